@@ -1,0 +1,144 @@
+"""ctypes binding of include/hwocr.h.
+
+There is no CPU fallback for the device functions: if libhwocr_hip.so is missing or a launch fails this module
+raises.  The text library (host C++) is bound separately so that compare/merge work on a machine without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_long
+F = C.c_float
+
+
+class HwocrError(RuntimeError):
+    pass
+
+
+_CODES = {1: "HWOCR_EINVAL (argument rejected by the launcher)", 2: "HWOCR_ELAUNCH (HIP launch failed)"}
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise HwocrError(f"{what or 'hwocr call'} failed: {_CODES.get(rc, rc)}")
+
+
+class VitBlock(C.Structure):
+    _fields_ = [(n, P) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_w", "ln2_b",
+                                  "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class Vit(C.Structure):
+    _fields_ = [(n, I) for n in ("depth", "dim", "heads", "mlp_dim", "patch", "merge", "tps", "kpad", "out_dim")] + [
+        ("eps", F), ("patch_w", P), ("blocks", C.POINTER(VitBlock)),
+        ("merger_ln_w", P), ("merger_ln_b", P), ("merger_fc1_w", P), ("merger_fc1_b", P),
+        ("merger_fc2_w", P), ("merger_fc2_b", P), ("rope_cos", P), ("rope_sin", P), ("pixel_lut", P)]
+
+
+class VitWs(C.Structure):
+    _fields_ = [(n, P) for n in ("patches", "x", "xn", "qkv", "q", "k", "vt", "attn", "mlp", "merge_mid")]
+
+
+class DecLayer(C.Structure):
+    _fields_ = [(n, P) for n in ("in_norm_w", "qkv_w", "qkv_b", "o_w", "post_norm_w", "gate_up_w", "down_w")]
+
+
+class Decoder(C.Structure):
+    _fields_ = [(n, I) for n in ("layers", "hidden", "Hq", "Hkv", "inter", "vocab", "sec0", "sec1")] + [
+        ("eps", F), ("embed", P), ("lm_head", P), ("final_norm_w", P), ("L", C.POINTER(DecLayer)),
+        ("rope_cos", P), ("rope_sin", P)]
+
+
+class Kv(C.Structure):
+    _fields_ = [("k", P), ("vt", P), ("nseq_max", I), ("ctx", I)]
+
+
+class DecWs(C.Structure):
+    _fields_ = [(n, P) for n in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "logits")]
+
+
+class GenState(C.Structure):
+    _fields_ = [(n, P) for n in ("cur_ids", "lens", "n_gen", "finished", "out_tokens", "rope_delta")] + [
+        ("max_new", I), ("min_new", I), ("n_eos", I), ("pad_id", I), ("eos", I * 4)]
+
+
+_HIP_SIGS = {
+    "hwocr_abi_version": ([], I),
+    "hwocr_gemm_wide": ([P, P, P, P, P, I, I, I, I, I, I, I, I, P], I),
+    "hwocr_gemm_skinny": ([P, P, P, P, I, I, I, I, I, I, I, I, P], I),
+    "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, P], I),
+    "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, P], I),
+    "hwocr_patchify": ([P, P, P, I, I, I, I, I, I, I, I, P], I),
+    "hwocr_layernorm": ([P, P, P, P, I, I, I, I, F, P], I),
+    "hwocr_add_rmsnorm": ([P, I, L, I, P, P, I, P, P, I, P, I, I, F, I, P], I),
+    "hwocr_vit_rope_split": ([P, P, P, P, P, P, P, P, I, I, I, I, P], I),
+    "hwocr_mrope_kv_prefill": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, P], I),
+    "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, P], I),
+    "hwocr_embed_splice": ([P, P, P, P, P, I, I, F, P], I),
+    "hwocr_argmax_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P], I),
+    "hwocr_vit_forward": ([C.POINTER(Vit), C.POINTER(VitWs), P, I, I, I, I, P, P, P, P, P], I),
+    "hwocr_prefill": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), P, P, P, P, P, P,
+                       I, I, I, I, P], I),
+    "hwocr_decode_step": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), I, I, P], I),
+    "hwocr_decode_graph_create": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), I, I,
+                                   C.POINTER(P)], I),
+    "hwocr_decode_graph_launch": ([P, I, P], I),
+    "hwocr_decode_graph_destroy": ([P], I),
+}
+
+_TEXT_SIGS = {
+    "hwocr_levenshtein_u32": ([P, C.c_int64, P, C.c_int64], C.c_int64),
+    "hwocr_lcs_align_u32": ([P, C.c_int64, P, C.c_int64, P], I),
+}
+
+HIP_SYMBOLS = tuple(_HIP_SIGS)
+TEXT_SYMBOLS = tuple(_TEXT_SIGS)
+
+_hip = None
+_text = None
+
+
+def _bind(path: str, sigs: dict) -> C.CDLL:
+    lib = C.CDLL(path)
+    for name, (argtypes, restype) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return lib
+
+
+def hip() -> C.CDLL:
+    """The device library.  Raises if it has not been built (no fallback path exists)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(_build.HIP_LIB):
+            raise HwocrError(
+                f"{_build.HIP_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "the page-read engine has no CPU fallback")
+        _hip = _bind(_build.HIP_LIB, _HIP_SIGS)
+    return _hip
+
+
+def text() -> C.CDLL:
+    global _text
+    if _text is None:
+        if not os.path.exists(_build.TEXT_LIB):
+            _build.build_text()
+        _text = _bind(_build.TEXT_LIB, _TEXT_SIGS)
+    return _text
+
+
+def ptr(t) -> C.c_void_p:
+    """Device/host pointer of a torch tensor (or None)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_handle():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

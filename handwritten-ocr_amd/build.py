@@ -1,0 +1,73 @@
+"""In-tree build of the native libraries (no JIT cache: the .so files travel with the source tree).
+
+  csrc/libhwocr_hip.so   hipcc --offload-arch=gfx950   gemm / attention / elementwise / runtime
+  csrc/libhwocr_text.so  g++                            Levenshtein / LCS alignment (host)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+HIP_SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "runtime.hip"]
+HIP_LIB = os.path.join(CSRC, "libhwocr_hip.so")
+TEXT_LIB = os.path.join(CSRC, "libhwocr_text.so")
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def _run(cmd: list[str]) -> None:
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the page-read engine needs the ROCm toolchain to build")
+
+
+def build_hip(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.cuh"), os.path.join(INCLUDE, "hwocr.h")]
+    if not force and _newer(HIP_LIB, deps):
+        return HIP_LIB
+    objs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        if force or not _newer(o, [s, deps[-2], deps[-1]]):
+            _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
+                  "-I" + INCLUDE, "-c", s, "-o", o])
+        objs.append(o)
+    _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
+    return HIP_LIB
+
+
+def build_text(force: bool = False) -> str:
+    src = os.path.join(CSRC, "text.cpp")
+    if not force and _newer(TEXT_LIB, [src, os.path.join(INCLUDE, "hwocr.h")]):
+        return TEXT_LIB
+    _run(["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-I" + INCLUDE, src, "-o", TEXT_LIB])
+    return TEXT_LIB
+
+
+def build_all(force: bool = False) -> None:
+    build_text(force)
+    build_hip(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("built", HIP_LIB, TEXT_LIB)

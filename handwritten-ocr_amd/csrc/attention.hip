@@ -1,0 +1,430 @@
+// Attention kernels of the page-read path (gfx950 / MI355X).
+//
+//  attn_prefill : flash-style attention over whole segments (one page image in the vision tower,
+//                 one prompt in decoder prefill).  Replaces F.scaled_dot_product_attention as reached
+//                 from HF modeling_qwen2_vl.py:375-418 (vision, non-causal, one segment per image) and
+//                 :553-569 (decoder prefill, causal, GQA).  The score tile is computed TRANSPOSED
+//                 (S^T = K.Q^T, 32x32x16 MFMA) so every lane owns one query column: softmax statistics
+//                 are lane-local (+1 exchange with lane^32) and the fp32 score registers, packed to bf16,
+//                 are directly the B operand of O^T += V^T.P^T — P never touches LDS.  V is consumed
+//                 through a transposed image V^T[d][key] that the rope/split kernels write.
+//  attn_decode  : one new token per read against its KV cache (HBM-bound).  K rows and V^T rows go
+//                 straight from HBM to MFMA operands; keys are split over waves and workgroups and merged
+//                 with the usual (m, l, O) rule.
+#include "common.cuh"
+#include "hwocr.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+
+struct PrefillArgs {
+  const bf16* Q; const bf16* K; const bf16* VT; bf16* O; const int* lens;
+  long q_seg, q_head, q_row;
+  long k_seg, k_head, k_row;
+  long v_seg, v_head, v_row;
+  long o_seg, o_row;
+  int group;          // query heads per kv head
+  float scale_log2;   // softmax scale * log2(e)
+};
+
+__device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
+  constexpr int HDP = (HD + 31) / 32 * 32;  // d rows of the V^T tile, padded to whole 32-row MFMA tiles
+  constexpr int KS = HD * 2 + 16;           // K tile row stride (bytes): +1 slot -> conflict-free ds_read_b128
+  constexpr int VS = 136;                   // V^T tile row stride (bytes): 64 keys + 8 B -> conflict-free ds_read_b64
+  constexpr int KBYTES = 64 * KS, VBYTES = HDP * VS;
+  constexpr int NS = HD / 16, ND = HDP / 32;
+  constexpr int CK = 64 * HD / 8, CV = HD * 8;             // 16-byte chunks per tile
+  constexpr int NKC = (CK + 255) / 256, NVC = (CV + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int seg = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+  const int len = a.lens[seg];
+  if (q0 >= len) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int hk = h / a.group;
+  const bf16* Qp = a.Q + seg * a.q_seg + h * a.q_head;
+  const bf16* Kp = a.K + seg * a.k_seg + hk * a.k_head;
+  const bf16* Vp = a.VT + seg * a.v_seg + hk * a.v_head;
+
+  const int qi = q0 + 32 * w + r;  // this lane's query column
+  bf16x8 qf[NS];
+  {
+    const bf16* qrow = Qp + (long)min(qi, len - 1) * a.q_row + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *(const bf16x8*)(qrow + 16 * s);
+  }
+
+  const int kv_end = CAUSAL ? min(len, q0 + 128) : len;
+  const int nt = (kv_end + 63) >> 6;
+
+  bf16x8 kreg[NKC], vreg[NVC];
+  auto load_tile = [&](int t) {
+    const int j0 = t * 64;
+#pragma unroll
+    for (int i = 0; i < NKC; ++i) {
+      const int id = tid + 256 * i;
+      if (id < CK) {
+        const int row = id / (HD / 8), ch = id % (HD / 8);
+        kreg[i] = *(const bf16x8*)(Kp + (long)min(j0 + row, len - 1) * a.k_row + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVC; ++i) {
+      const int id = tid + 256 * i;
+      if (id < CV) {
+        const int d = id >> 3, ch = id & 7;
+        bf16x8 v = *(const bf16x8*)(Vp + (long)d * a.v_row + j0 + ch * 8);
+        if (j0 + 64 > len) {  // tail tile: keys past the segment carry p = 0, keep 0 * x finite
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (j0 + ch * 8 + e >= len) v[e] = (bf16)0.0f;
+        }
+        vreg[i] = v;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* kb = smem + buf * (KBYTES + VBYTES);
+    char* vb = kb + KBYTES;
+#pragma unroll
+    for (int i = 0; i < NKC; ++i) {
+      const int id = tid + 256 * i;
+      if (id < CK) {
+        const int row = id / (HD / 8), ch = id % (HD / 8);
+        *(bf16x8*)(kb + row * KS + ch * 16) = kreg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVC; ++i) {
+      const int id = tid + 256 * i;
+      if (id < CV) {
+        const int d = id >> 3, ch = id & 7;
+        char* p = vb + d * VS + ch * 16;
+        const bf16x8 v = vreg[i];
+        *(bf16x4*)p = bf16x4{v[0], v[1], v[2], v[3]};
+        *(bf16x4*)(p + 8) = bf16x4{v[4], v[5], v[6], v[7]};
+      }
+    }
+  };
+
+  f32x16 o[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  float m = NEG_BIG, l = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int j0 = t * 64;
+    if (t + 1 < nt) load_tile(t + 1);
+    const char* kb = smem + (t & 1) * (KBYTES + VBYTES);
+    const char* vb = kb + KBYTES;
+
+    // ---- S^T = K . Q^T : rows = keys (registers), column = this lane's query
+    f32x16 s0, s1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const bf16x8 k0 = *(const bf16x8*)(kb + r * KS + (16 * s + 8 * hh) * 2);
+      const bf16x8 k1 = *(const bf16x8*)(kb + (32 + r) * KS + (16 * s + 8 * hh) * 2);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+    }
+    const bool need_mask = (j0 + 64 > len) || (CAUSAL && (j0 + 63 > q0 + 32 * w));
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v0 = s0[i] * a.scale_log2, v1 = s1[i] * a.scale_log2;
+      if (need_mask) {
+        const int key = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (key >= len || (CAUSAL && key > qi)) v0 = -INFINITY;
+        if (key + 32 >= len || (CAUSAL && key + 32 > qi)) v1 = -INFINITY;
+      }
+      s0[i] = v0; s1[i] = v1;
+      mx = fmaxf(mx, fmaxf(v0, v1));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = exp2f(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s0[i] = exp2f(s0[i] - m_new);
+      s1[i] = exp2f(s1[i] - m_new);
+      rs += s0[i] + s1[i];
+    }
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+
+    // ---- P^T as B operand: k-step (kt, s2) element j <-> key 32kt + 16s2 + 8(j>>2) + 4hh + (j&3)
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pb[0][s2][j] = f2bf(s0[8 * s2 + j]);
+        pb[1][s2][j] = f2bf(s1[8 * s2 + j]);
+      }
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const char* p = vb + (d * 32 + r) * VS + (kt * 32 + 16 * s2 + 4 * hh) * 2;
+          const bf16x8 vf = cat4(*(const bf16x4*)p, *(const bf16x4*)(p + 16));
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt][s2], o[d], 0, 0, 0);
+        }
+
+    if (t + 1 < nt) store_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / l;
+  if (qi < len) {
+    bf16* orow = a.O + seg * a.o_seg + (long)qi * a.o_row + h * HD;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * hh;
+        if (dd < HD) {
+          bf16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[d][4 * g + e] * inv);
+          *(bf16x4*)(orow + dd) = ov;
+        }
+      }
+  }
+}
+
+template <int HD, bool CAUSAL>
+int launch_prefill(const PrefillArgs& a, int nseg, int heads, int max_len, hipStream_t st) {
+  constexpr int HDP = (HD + 31) / 32 * 32;
+  constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HDP * 136);
+  static bool done = false;
+  if (!done) {
+    hipFuncSetAttribute((const void*)attn_prefill_kernel<HD, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    done = true;
+  }
+  dim3 grid((max_len + 127) / 128, heads, nseg), block(256);
+  hipLaunchKernelGGL((attn_prefill_kernel<HD, CAUSAL>), grid, block, LDS, st, a);
+  return hwocr_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode attention
+// ------------------------------------------------------------------------------------------------
+struct DecodeArgs {
+  const bf16* Q; const bf16* K; const bf16* VT; const int* lens;
+  float* part_o; float* part_ml; bf16* out;
+  long k_seq, k_head, v_seq, v_head, v_row;
+  int Hq, Hkv, G, nsplit;
+  float scale_log2;
+};
+
+constexpr int DEC_HD = 128;
+
+__global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs a) {
+  __shared__ float s_o[4][DEC_HD][16];
+  __shared__ float s_m[4][16];
+  __shared__ float s_l[4][16];
+  const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, qd = lane >> 4;
+  const int len = a.lens[b];
+  const bf16* Kp = a.K + b * a.k_seq + hk * a.k_head;
+  const bf16* Vp = a.VT + b * a.v_seq + hk * a.v_head;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (c < a.G)
+      qf[s] = *(const bf16x8*)(a.Q + ((long)b * a.Hq + hk * a.G + c) * DEC_HD + 32 * s + 8 * qd);
+    else
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)0.0f;
+  }
+
+  f32x4 o[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = NEG_BIG, l = 0.f;
+
+  const int nblk = (len + 63) >> 6;
+  for (int kb = split * 4 + w; kb < nblk; kb += a.nsplit * 4) {
+    const int k0 = kb * 64;
+    bf16x8 kf[4][4];
+    bf16x4 vt[8][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16* krow = Kp + (long)min(k0 + 16 * t + c, len - 1) * DEC_HD + 8 * qd;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[t][s] = *(const bf16x8*)(krow + 32 * s);
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const bf16* vrow = Vp + (long)(16 * d + c) * a.v_row + k0 + 4 * qd;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vt[d][u] = *(const bf16x4*)(vrow + 16 * u);
+    }
+    if (k0 + 64 > len) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + 16 * u + 4 * qd + e >= len) vt[d][u][e] = (bf16)0.0f;
+    }
+    // S^T tiles: rows = keys 16t + 4qd + r, column = query c
+    f32x4 sc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][s], qf[s], sc[t], 0, 0, 0);
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = sc[t][e] * a.scale_log2;
+        if (k0 + 16 * t + 4 * qd + e >= len) v = -INFINITY;
+        sc[t][e] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = exp2f(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[t][e] = exp2f(sc[t][e] - m_new);
+        rs += sc[t][e];
+      }
+    l = l * alpha + rs;
+    m = m_new;
+    // P^T as B operand: k slot (qd, j): j<4 -> tile 2u key 4qd+j ; j>=4 -> tile 2u+1 key 4qd+j-4
+    bf16x8 pb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pb[u][e] = f2bf(sc[2 * u][e]);
+        pb[u][4 + e] = f2bf(sc[2 * u + 1][e]);
+      }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      o[d] *= alpha;
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat4(vt[d][0], vt[d][1]), pb[0], o[d], 0, 0, 0);
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat4(vt[d][2], vt[d][3]), pb[1], o[d], 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+
+  // ---- merge the 4 waves through LDS; o[d][e] = O^T[16d + 4qd + e][query c]
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_o[w][16 * d + 4 * qd + e][c] = o[d][e];
+  if (qd == 0) { s_m[w][c] = m; s_l[w][c] = l; }
+  __syncthreads();
+  for (int idx = tid; idx < a.G * DEC_HD; idx += 256) {
+    const int qq = idx / DEC_HD, d = idx % DEC_HD;
+    float M = fmaxf(fmaxf(s_m[0][qq], s_m[1][qq]), fmaxf(s_m[2][qq], s_m[3][qq]));
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+      const float f = exp2f(s_m[ww][qq] - M);
+      L += s_l[ww][qq] * f;
+      O += s_o[ww][d][qq] * f;
+    }
+    if (a.nsplit == 1) {
+      a.out[((long)b * a.Hq + hk * a.G + qq) * DEC_HD + d] = f2bf(O / L);
+    } else {
+      const long base = (((long)b * a.Hkv + hk) * a.nsplit + split) * a.G;
+      a.part_o[(base + qq) * DEC_HD + d] = O;
+      if (d == 0) { a.part_ml[(base + qq) * 2] = M; a.part_ml[(base + qq) * 2 + 1] = L; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_decode_merge_kernel(DecodeArgs a) {
+  const int hk = blockIdx.x, b = blockIdx.y;
+  for (int idx = threadIdx.x; idx < a.G * DEC_HD; idx += 256) {
+    const int qq = idx / DEC_HD, d = idx % DEC_HD;
+    const long base = ((long)b * a.Hkv + hk) * a.nsplit * a.G;
+    float M = NEG_BIG;
+    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.part_ml[(base + s * a.G + qq) * 2]);
+    float L = 0.f, O = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) {
+      const long e = base + s * a.G + qq;
+      const float f = exp2f(a.part_ml[e * 2] - M);
+      L += a.part_ml[e * 2 + 1] * f;
+      O += a.part_o[e * DEC_HD + d] * f;
+    }
+    a.out[((long)b * a.Hq + hk * a.G + qq) * DEC_HD + d] = f2bf(O / L);
+  }
+}
+
+}  // namespace
+
+extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, void* O, const int* lens,
+                                  int nseg, int heads, int group, int head_dim, int max_len, int causal,
+                                  long q_seg, long q_head, long q_row, long k_seg, long k_head, long k_row,
+                                  long v_seg, long v_head, long v_row, long o_seg, long o_row, float scale,
+                                  hipStream_t stream) {
+  if (nseg <= 0 || heads <= 0 || group <= 0 || max_len <= 0) return HWOCR_EINVAL;
+  if ((q_row % 8) || (k_row % 8) || (v_row % 8) || (o_row % 4) || (q_head % 8) || (k_head % 8) || (v_head % 8) ||
+      (q_seg % 8) || (k_seg % 8) || (v_seg % 8))
+    return HWOCR_EINVAL;
+  PrefillArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, (bf16*)O, lens,
+                q_seg, q_head, q_row, k_seg, k_head, k_row, v_seg, v_head, v_row, o_seg, o_row,
+                group, scale * 1.4426950408889634f};
+  if (head_dim == 80) return causal ? launch_prefill<80, true>(a, nseg, heads, max_len, stream)
+                                    : launch_prefill<80, false>(a, nseg, heads, max_len, stream);
+  if (head_dim == 128) return causal ? launch_prefill<128, true>(a, nseg, heads, max_len, stream)
+                                     : launch_prefill<128, false>(a, nseg, heads, max_len, stream);
+  if (head_dim == 64) return causal ? launch_prefill<64, true>(a, nseg, heads, max_len, stream)
+                                    : launch_prefill<64, false>(a, nseg, heads, max_len, stream);
+  if (head_dim == 32) return causal ? launch_prefill<32, true>(a, nseg, heads, max_len, stream)
+                                    : launch_prefill<32, false>(a, nseg, heads, max_len, stream);
+  return HWOCR_EINVAL;
+}
+
+extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out,
+                                 float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit,
+                                 long k_seq, long k_head, long v_seq, long v_head, long v_row, float scale,
+                                 hipStream_t stream) {
+  if (nseq <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16 || nsplit < 1) return HWOCR_EINVAL;
+  if (nsplit > 1 && (!part_o || !part_ml)) return HWOCR_EINVAL;
+  if ((v_row % 64) || (k_seq % 8) || (k_head % 8) || (v_seq % 8) || (v_head % 8)) return HWOCR_EINVAL;
+  DecodeArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, lens, part_o, part_ml, (bf16*)out,
+               k_seq, k_head, v_seq, v_head, v_row, Hq, Hkv, Hq / Hkv, nsplit, scale * 1.4426950408889634f};
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+  if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(Hkv, nseq), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}

@@ -1,0 +1,54 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the page-read path.
+// Wave = 64 lanes everywhere; bf16 storage, fp32 accumulation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define HWOCR_OK 0
+#define HWOCR_EINVAL 1
+#define HWOCR_ELAUNCH 2
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }   // RNE (v_cvt_pk_bf16_f32)
+// value after a round trip through bf16: reproduces the places where the reference's
+// bf16 modules materialise an intermediate tensor.
+// The widening goes through integer bits on purpose: written as (float)(bf16)x, LLVM's contraction folds
+// fpext(fptrunc(a*b)) + c into fma(a, b, c) and silently drops the rounding.
+__device__ __forceinline__ float rbf(float x) {
+  const bf16 b = (bf16)x;
+  return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: hardware deals consecutive ids round-robin
+// over the 8 XCDs; after the remap each XCD owns one contiguous chunk of logical ids, so tiles
+// that share operand panels share an L2. Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = orig & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (orig >> 3);
+}
+
+static inline int hwocr_launch_status() {
+  return hipGetLastError() == hipSuccess ? HWOCR_OK : HWOCR_ELAUNCH;
+}

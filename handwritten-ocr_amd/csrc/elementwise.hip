@@ -1,0 +1,512 @@
+// Row-wise / gather / scatter kernels of the page-read path (gfx950 / MI355X).  All HBM-bound: 16-byte
+// vector accesses, one wave per row for the norms, LDS tiles wherever a transpose is needed.
+// Every kernel cites the reference-side operation it replaces (HF = transformers, the library the
+// reference's run_ocr calls at ocr_agent/tools.py:756-769).
+#include "common.cuh"
+#include "hwocr.h"
+
+namespace {
+
+constexpr int MAXC = 4;  // 16-byte chunks per lane per row -> row width <= 64*8*4 = 2048
+
+// ------------------------------------------------------------------------------------------------
+// patchify: resized uint8 page -> bf16 patch rows.  Replaces rescale + normalize + patchify of
+// HF image_processing_pil_qwen2_vl.py:152-187,:226-229 followed by the .to(bf16) of PatchEmbed
+// (modeling_qwen2_vl.py:266-274).  (v/255 - mean)/std for the 256 pixel values x 3 channels is a host-built
+// table (same numpy arithmetic as the reference library), so the kernel is an exact gather.
+// Row order: (gh/m, gw/m, m, m); column order: (C, T, ph, pw), T = temporal duplicate.
+// ------------------------------------------------------------------------------------------------
+struct PatchifyArgs {
+  const uint8_t* img; const bf16* lut; bf16* out;
+  int nimg, H, W, gh, gw, patch, merge, tps, kreal, kpad, img_ld;
+};
+__global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a) {
+  const int chunks = a.kpad >> 3;
+  const long total = (long)a.nimg * a.gh * a.gw * chunks;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int ch = gid % chunks;
+  const long row = gid / chunks;
+  const int P = a.gh * a.gw;
+  const int im = row / P, p = row % P;
+  const int mm = a.merge * a.merge;
+  const int blk = p / mm, within = p % mm;
+  const int bw_n = a.gw / a.merge;
+  const int pr = (blk / bw_n) * a.merge + within / a.merge;
+  const int pc = (blk % bw_n) * a.merge + within % a.merge;
+  const int pp = a.patch * a.patch;
+  const uint8_t* base = a.img + (long)im * a.H * a.W * 3;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = ch * 8 + e;
+    bf16 v = (bf16)0.0f;
+    if (k < a.kreal) {
+      const int c = k / (a.tps * pp);
+      const int rem = k % pp;
+      const int py = rem / a.patch, px = rem % a.patch;
+      const uint8_t pix = base[((long)(pr * a.patch + py) * a.W + (pc * a.patch + px)) * 3 + c];
+      v = a.lut[c * 256 + pix];
+    }
+    o[e] = v;
+  }
+  *(bf16x8*)(a.out + ((long)im * a.img_ld + p) * a.kpad + ch * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (vision tower: HF modeling_qwen2_vl.py:428-429, merger ln_q :281).  fp32 statistics,
+// one rounding at the end, as nn.LayerNorm does on a bf16 tensor.
+// ------------------------------------------------------------------------------------------------
+struct LayerNormArgs { const bf16* x; const bf16* w; const bf16* b; bf16* out; int rows, D, ldx, ldo; float eps; };
+__global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= a.rows) return;
+  const int nch = a.D >> 3;
+  float x[MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const bf16x8 v = *(const bf16x8*)(a.x + (long)row * a.ldx + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[i][e] = bf2f(v[e]); s += x[i][e]; }
+    }
+  }
+  const float mean = wave_sum(s) / a.D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < nch)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mean; ss += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / a.D + a.eps);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const bf16x8 g = *(const bf16x8*)(a.w + ch * 8);
+      const bf16x8 bb = *(const bf16x8*)(a.b + ch * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf((x[i][e] - mean) * rstd * bf2f(g[e]) + bf2f(bb[e]));
+      *(bf16x8*)(a.out + (long)row * a.ldo + ch * 8) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (split-K combine + bias + residual) + RMSNorm.  Replaces Qwen2VLRMSNorm (HF modeling_qwen2_vl.py:96-110:
+// fp32 x*rsqrt(mean(x^2)+eps) -> cast to bf16 -> weight * that) and the two residual adds of the decoder
+// layer (:591-600).  With slabs: h <- bf16(bf16(sum slabs + bias) + h) is written back first.
+// row_index (optional) gathers source rows (last prompt token of every read before the LM head).
+// ------------------------------------------------------------------------------------------------
+struct RmsArgs {
+  const float* slabs; int nslab; long slab_stride; int ld_slab;
+  const bf16* bias; bf16* h; int ldh;
+  const bf16* w; bf16* out; int ldo;
+  const int* row_index; int rows, D; float eps; int gemma;
+};
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(RmsArgs a) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= a.rows) return;
+  const int src = a.row_index ? a.row_index[row] : row;
+  const int nch = a.D >> 3;
+  float x[MAXC][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const bf16x8 hv = *(const bf16x8*)(a.h + (long)src * a.ldh + ch * 8);
+      if (a.nslab > 0) {
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = 0.f;
+        for (int s = 0; s < a.nslab; ++s) {
+          const float* p = a.slabs + s * a.slab_stride + (long)src * a.ld_slab + ch * 8;
+          const f32x4 p0 = *(const f32x4*)p, p1 = *(const f32x4*)(p + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { y[e] += p0[e]; y[4 + e] += p1[e]; }
+        }
+        if (a.bias) {
+          const bf16x8 bb = *(const bf16x8*)(a.bias + ch * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] += bf2f(bb[e]);
+        }
+        bf16x8 hn;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hn[e] = f2bf(rbf(y[e]) + bf2f(hv[e])); x[i][e] = bf2f(hn[e]); }
+        *(bf16x8*)(a.h + (long)src * a.ldh + ch * 8) = hn;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[i][e] = bf2f(hv[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += x[i][e] * x[i][e];
+    }
+  }
+  if (!a.out) return;
+  const float rstd = rsqrtf(wave_sum(ss) / a.D + a.eps);
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int ch = lane + 64 * i;
+    if (ch < nch) {
+      const bf16x8 g = *(const bf16x8*)(a.w + ch * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o[e] = a.gemma ? f2bf(x[i][e] * rstd * (1.0f + bf2f(g[e]))) : f2bf(bf2f(g[e]) * rbf(x[i][e] * rstd));
+      *(bf16x8*)(a.out + (long)row * a.ldo + ch * 8) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vision rope + head split.  qkv[token][3][head][hd] -> Q,K [head][token][hd] (rotated, fp32 math then one
+// rounding: HF apply_rotary_pos_emb_vision modeling_qwen2_vl.py:239-248) and V^T [head][hd][token].
+// ------------------------------------------------------------------------------------------------
+struct VitRopeArgs {
+  const bf16* qkv; bf16* Q; bf16* K; bf16* VT;
+  const int* pos_h; const int* pos_w; const float* cos_tab; const float* sin_tab;
+  int tokens, tok_ld, heads, hd; long q_head_stride, vt_head_stride;
+};
+__global__ __launch_bounds__(256) void vit_rope_split_kernel(VitRopeArgs a) {
+  __shared__ bf16 s_v[128][72];
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, tid = threadIdx.x;
+  const int hd = a.hd, half = hd >> 1, quarter = hd >> 2;
+  const int D = a.heads * hd;
+  const int per_tok = hd >> 4;  // (d, d+half) chunk pairs per token
+  for (int id = tid; id < 64 * per_tok * 2; id += 256) {
+    const int which = id / (64 * per_tok);  // 0 = q, 1 = k
+    const int rem = id % (64 * per_tok);
+    const int tt = rem / per_tok, j = rem % per_tok;
+    const int tok = t0 + tt;
+    if (tok >= a.tokens) continue;
+    const bf16* src = a.qkv + (long)tok * 3 * D + which * D + h * hd + 8 * j;
+    const bf16x8 va = *(const bf16x8*)src, vb = *(const bf16x8*)(src + half);
+    const int ph = a.pos_h[tok], pw = a.pos_w[tok];
+    bf16x8 oa, ob;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = 8 * j + e;
+      const int p = d < quarter ? ph : pw;
+      const int f = d < quarter ? d : d - quarter;
+      const float cs = a.cos_tab[p * quarter + f], sn = a.sin_tab[p * quarter + f];
+      const float x1 = bf2f(va[e]), x2 = bf2f(vb[e]);
+      oa[e] = f2bf(__fadd_rn(__fmul_rn(x1, cs), __fmul_rn(-x2, sn)));
+      ob[e] = f2bf(__fadd_rn(__fmul_rn(x2, cs), __fmul_rn(x1, sn)));
+    }
+    bf16* dst = (which ? a.K : a.Q) + h * a.q_head_stride + (long)tok * hd + 8 * j;
+    *(bf16x8*)dst = oa;
+    *(bf16x8*)(dst + half) = ob;
+  }
+  // V: [64 tokens][hd] -> LDS transposed -> V^T rows of 64 tokens (zeros past the last token)
+  const int vch = hd >> 3;
+  for (int id = tid; id < 64 * vch; id += 256) {
+    const int tt = id / vch, j = id % vch;
+    const int tok = t0 + tt;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.0f;
+    if (tok < a.tokens) v = *(const bf16x8*)(a.qkv + (long)tok * 3 * D + 2 * D + h * hd + 8 * j);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_v[8 * j + e][tt] = v[e];
+  }
+  __syncthreads();
+  for (int id = tid; id < hd * 8; id += 256) {
+    const int d = id >> 3, c8 = id & 7;
+    if (t0 + c8 * 8 < a.tok_ld) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = s_v[d][c8 * 8 + e];
+      *(bf16x8*)(a.VT + h * a.vt_head_stride + (long)d * a.tok_ld + t0 + c8 * 8) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder M-RoPE + KV-cache write (prefill).  Replaces apply_multimodal_rotary_pos_emb
+// (HF modeling_qwen2_vl.py:196-222: bf16 cos/sin, every product and the sum rounded to bf16) and
+// DynamicLayer.update (HF cache_utils.py:127-145: torch.cat realloc) with an in-place append into
+// K[seq][kvh][slot][128] and V^T[seq][kvh][128][slot].
+// ------------------------------------------------------------------------------------------------
+struct MropeArgs {
+  const bf16* qkv; bf16* Q; bf16* K; bf16* VT;
+  const int* pos;  // pos[3][rows]
+  const bf16* cos_tab; const bf16* sin_tab;                  // [maxpos][64]
+  int rows, rows_per_seq, Hq, Hkv, sec0, sec1;
+  long k_seq, k_head, v_seq, v_head, v_row;
+};
+constexpr int DHD = 128;
+
+__device__ __forceinline__ void mrope_pair(const bf16x8 va, const bf16x8 vb, int d0, const int pt, const int ph,
+                                           const int pw, const MropeArgs& a, bf16x8& oa, bf16x8& ob) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int i = d0 + e;  // 0..63
+    const int p = i < a.sec0 ? pt : (i < a.sec1 ? ph : pw);
+    const float cs = bf2f(a.cos_tab[p * 64 + i]), sn = bf2f(a.sin_tab[p * 64 + i]);
+    const float x1 = bf2f(va[e]), x2 = bf2f(vb[e]);
+    oa[e] = f2bf(rbf(x1 * cs) + rbf(-x2 * sn));
+    ob[e] = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
+  }
+}
+
+__global__ __launch_bounds__(256) void mrope_kv_prefill_kernel(MropeArgs a) {
+  __shared__ bf16 s_v[64][DHD + 2];
+  const int r0 = blockIdx.x * 64, hy = blockIdx.y, tid = threadIdx.x;
+  const int W = (a.Hq + 2 * a.Hkv) * DHD;
+  if (hy < a.Hq + a.Hkv) {
+    const bool isk = hy >= a.Hq;
+    const int col0 = isk ? a.Hq * DHD + (hy - a.Hq) * DHD : hy * DHD;
+    for (int id = tid; id < 64 * 8; id += 256) {
+      const int rr = id >> 3, j = id & 7;
+      const int row = r0 + rr;
+      if (row >= a.rows) continue;
+      const bf16* src = a.qkv + (long)row * W + col0 + 8 * j;
+      bf16x8 oa, ob;
+      mrope_pair(*(const bf16x8*)src, *(const bf16x8*)(src + 64), 8 * j, a.pos[row], a.pos[a.rows + row],
+                 a.pos[2 * a.rows + row], a, oa, ob);
+      const int sq = row / a.rows_per_seq, slot = row % a.rows_per_seq;
+      bf16* dst = isk ? a.K + sq * a.k_seq + (hy - a.Hq) * a.k_head + (long)slot * DHD + 8 * j
+                      : a.Q + (long)row * a.Hq * DHD + hy * DHD + 8 * j;
+      *(bf16x8*)dst = oa;
+      *(bf16x8*)(dst + 64) = ob;
+    }
+  } else {
+    const int hk = hy - a.Hq - a.Hkv;
+    for (int id = tid; id < 64 * 16; id += 256) {
+      const int rr = id >> 4, j = id & 15;
+      const int row = r0 + rr;
+      if (row >= a.rows) continue;
+      const bf16x8 v = *(const bf16x8*)(a.qkv + (long)row * W + (a.Hq + a.Hkv + hk) * DHD + 8 * j);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s_v[rr][8 * j + e] = v[e];
+    }
+    __syncthreads();
+    // lane <-> row: consecutive lanes hit consecutive cache slots, so each wave store is one 128-byte line
+    const int rr = tid & 63, dg = tid >> 6;
+    const int row = r0 + rr;
+    if (row < a.rows) {
+      bf16* dst = a.VT + (row / a.rows_per_seq) * a.v_seq + hk * a.v_head + row % a.rows_per_seq;
+      for (int d = dg * 32; d < dg * 32 + 32; ++d) dst[(long)d * a.v_row] = s_v[rr][d];
+    }
+  }
+}
+
+// Decode variant: one row per read, input = split-K slabs of the fused QKV projection (+bias).
+struct DecQkvArgs {
+  const float* slabs; int nslab; long slab_stride;
+  const bf16* bias; bf16* Q; bf16* K; bf16* VT;
+  const int* lens; const int* rope_delta;
+  const bf16* cos_tab; const bf16* sin_tab;
+  int Hq, Hkv; long k_seq, k_head, v_seq, v_head, v_row;
+};
+__global__ __launch_bounds__(256) void decode_qkv_finish_kernel(DecQkvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* row = (bf16*)smem;  // [(Hq+2Hkv)*128]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int W = (a.Hq + 2 * a.Hkv) * DHD;
+  for (int ch = tid; ch < W / 8; ch += 256) {
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = 0.f;
+    for (int s = 0; s < a.nslab; ++s) {
+      const float* p = a.slabs + s * a.slab_stride + (long)b * W + ch * 8;
+      const f32x4 p0 = *(const f32x4*)p, p1 = *(const f32x4*)(p + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { y[e] += p0[e]; y[4 + e] += p1[e]; }
+    }
+    if (a.bias) {
+      const bf16x8 bb = *(const bf16x8*)(a.bias + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] += bf2f(bb[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) row[ch * 8 + e] = f2bf(y[e]);
+  }
+  __syncthreads();
+  const int slot = a.lens[b] - 1;
+  const int p = slot + a.rope_delta[b];  // all three M-RoPE axes coincide on generated tokens
+  // q and k heads: pairs (d, d+64)
+  for (int id = tid; id < (a.Hq + a.Hkv) * 64; id += 256) {
+    const int hy = id >> 6, i = id & 63;
+    const float cs = bf2f(a.cos_tab[p * 64 + i]), sn = bf2f(a.sin_tab[p * 64 + i]);
+    const float x1 = bf2f(row[hy * DHD + i]), x2 = bf2f(row[hy * DHD + 64 + i]);
+    const bf16 oa = f2bf(rbf(x1 * cs) + rbf(-x2 * sn));
+    const bf16 ob = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
+    bf16* dst = hy < a.Hq ? a.Q + ((long)b * a.Hq + hy) * DHD
+                          : a.K + b * a.k_seq + (hy - a.Hq) * a.k_head + (long)slot * DHD;
+    dst[i] = oa;
+    dst[64 + i] = ob;
+  }
+  for (int id = tid; id < a.Hkv * DHD; id += 256) {
+    const int hk = id / DHD, d = id % DHD;
+    a.VT[b * a.v_seq + hk * a.v_head + (long)d * a.v_row + slot] = row[(a.Hq + a.Hkv) * DHD + id];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Token embedding gather + image-token splice (HF modeling_qwen2_vl.py get_placeholder_mask +
+// masked_scatter: image rows replace the <|image_pad|> embeddings).
+// ------------------------------------------------------------------------------------------------
+struct EmbedArgs { const int* ids; const int* img_row; const bf16* table; const bf16* img; bf16* out; int rows, D; float scale; };
+__global__ __launch_bounds__(256) void embed_splice_kernel(EmbedArgs a) {
+  const int chunks = a.D >> 3;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)a.rows * chunks) return;
+  const int row = gid / chunks, ch = gid % chunks;
+  const int ir = a.img_row ? a.img_row[row] : -1;
+  bf16x8 v = ir >= 0 ? *(const bf16x8*)(a.img + (long)ir * a.D + ch * 8)
+                     : *(const bf16x8*)(a.table + (long)a.ids[row] * a.D + ch * 8);
+  if (a.scale != 1.0f && ir < 0)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) * rbf(a.scale));
+  *(bf16x8*)(a.out + (long)row * a.D + ch * 8) = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Greedy token select + stop bookkeeping, all on device so a decode step never syncs with the host.
+// Replaces HF generation/utils.py:2894-2937: logits[:, -1].float() -> (min-new-tokens EOS suppression) ->
+// argmax -> pad finished rows -> append -> EOS stop flags.
+// ------------------------------------------------------------------------------------------------
+struct SelectArgs {
+  const bf16* logits; int ldl, V;
+  int* cur_ids; int* lens; int* n_gen; int* finished; int* out_tokens; int max_new, min_new;
+  int eos[4]; int n_eos; int pad_id;
+};
+__global__ __launch_bounds__(256) void argmax_advance_kernel(SelectArgs a) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bf16* row = a.logits + (long)b * a.ldl;
+  const bool suppress = a.n_gen[b] < a.min_new;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int ch = tid; ch < a.V / 8; ch += 256) {
+    const bf16x8 v = *(const bf16x8*)(row + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = bf2f(v[e]);
+      const int idx = ch * 8 + e;
+      if (suppress)
+        for (int k = 0; k < a.n_eos; ++k)
+          if (idx == a.eos[k]) x = -INFINITY;
+      if (x > best || (x == best && idx < bi)) { best = x; bi = idx; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { s_val[w] = best; s_idx[w] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 1; k < 4; ++k)
+      if (s_val[k] > best || (s_val[k] == best && s_idx[k] < bi)) { best = s_val[k]; bi = s_idx[k]; }
+    int tok = bi;
+    if (a.finished[b]) {
+      tok = a.pad_id;
+    } else {
+      for (int k = 0; k < a.n_eos; ++k)
+        if (tok == a.eos[k]) a.finished[b] = 1;
+    }
+    const int n = a.n_gen[b];
+    if (n < a.max_new) a.out_tokens[(long)b * a.max_new + n] = tok;
+    a.n_gen[b] = n + 1;
+    a.cur_ids[b] = tok;
+    a.lens[b] += 1;
+  }
+}
+
+}  // namespace
+
+extern "C" int hwocr_patchify(const void* img, const void* lut, void* out, int nimg, int H, int W, int patch,
+                              int merge, int tps, int kpad, int rows_per_img_ld, hipStream_t stream) {
+  if (nimg <= 0 || H % (patch * merge) || W % (patch * merge) || kpad % 8 || kpad < 3 * tps * patch * patch ||
+      rows_per_img_ld < (H / patch) * (W / patch))
+    return HWOCR_EINVAL;
+  PatchifyArgs a{(const uint8_t*)img, (const bf16*)lut, (bf16*)out, nimg, H, W, H / patch, W / patch,
+                 patch, merge, tps, 3 * tps * patch * patch, kpad, rows_per_img_ld};
+  const long total = (long)nimg * a.gh * a.gw * (kpad / 8);
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int D, int ldx,
+                               int ldo, float eps, hipStream_t stream) {
+  if (rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldx % 8 || ldo % 8) return HWOCR_EINVAL;
+  LayerNormArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)out, rows, D, ldx, ldo, eps};
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_add_rmsnorm(const float* slabs, int nslab, long slab_stride, int ld_slab, const void* bias,
+                                 void* h, int ldh, const void* w, void* out, int ldo, const int* row_index,
+                                 int rows, int D, float eps, int gemma, hipStream_t stream) {
+  if (rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldh % 8 || ldo % 8 || (nslab > 0 && (!slabs || ld_slab % 4)))
+    return HWOCR_EINVAL;
+  if (nslab > 0 && row_index) return HWOCR_EINVAL;
+  RmsArgs a{slabs, nslab, slab_stride, ld_slab, (const bf16*)bias, (bf16*)h, ldh, (const bf16*)w, (bf16*)out, ldo,
+            row_index, rows, D, eps, gemma};
+  hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_vit_rope_split(const void* qkv, void* Q, void* K, void* VT, const int* pos_h, const int* pos_w,
+                                    const float* cos_tab, const float* sin_tab, int tokens, int tok_ld, int heads,
+                                    int hd, hipStream_t stream) {
+  if (tokens <= 0 || tok_ld % 64 || tok_ld < tokens || hd % 16 || hd > 128) return HWOCR_EINVAL;
+  VitRopeArgs a{(const bf16*)qkv, (bf16*)Q, (bf16*)K, (bf16*)VT, pos_h, pos_w, cos_tab, sin_tab,
+                tokens, tok_ld, heads, hd, (long)tok_ld * hd, (long)hd * tok_ld};
+  hipLaunchKernelGGL(vit_rope_split_kernel, dim3((tok_ld + 63) / 64, heads), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_mrope_kv_prefill(const void* qkv, void* Q, void* K, void* VT, const int* pos,
+                                      const void* cos_tab, const void* sin_tab, int rows, int rows_per_seq, int Hq,
+                                      int Hkv, int sec0, int sec1, long k_seq, long k_head, long v_seq, long v_head,
+                                      long v_row, hipStream_t stream) {
+  if (rows <= 0 || Hq <= 0 || Hkv <= 0 || rows_per_seq <= 0 || rows_per_seq > v_row) return HWOCR_EINVAL;
+  MropeArgs a{(const bf16*)qkv, (bf16*)Q, (bf16*)K, (bf16*)VT, pos, (const bf16*)cos_tab,
+              (const bf16*)sin_tab, rows, rows_per_seq, Hq, Hkv, sec0, sec1, k_seq, k_head, v_seq, v_head, v_row};
+  hipLaunchKernelGGL(mrope_kv_prefill_kernel, dim3((rows + 63) / 64, Hq + 2 * Hkv), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_stride, const void* bias, void* Q,
+                                       void* K, void* VT, const int* lens, const int* rope_delta,
+                                       const void* cos_tab, const void* sin_tab, int nseq, int Hq, int Hkv,
+                                       long k_seq, long k_head, long v_seq, long v_head, long v_row,
+                                       hipStream_t stream) {
+  if (nseq <= 0 || nslab < 1 || !slabs) return HWOCR_EINVAL;
+  DecQkvArgs a{slabs, nslab, slab_stride, (const bf16*)bias, (bf16*)Q, (bf16*)K, (bf16*)VT, lens, rope_delta,
+               (const bf16*)cos_tab, (const bf16*)sin_tab, Hq, Hkv, k_seq, k_head, v_seq, v_head, v_row};
+  hipLaunchKernelGGL(decode_qkv_finish_kernel, dim3(nseq), dim3(256), (size_t)(Hq + 2 * Hkv) * DHD * 2, stream, a);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_embed_splice(const int* ids, const int* img_row, const void* table, const void* img, void* out,
+                                  int rows, int D, float scale, hipStream_t stream) {
+  if (rows <= 0 || D % 8) return HWOCR_EINVAL;
+  EmbedArgs a{ids, img_row, (const bf16*)table, (const bf16*)img, (bf16*)out, rows, D, scale};
+  const long total = (long)rows * (D / 8);
+  hipLaunchKernelGGL(embed_splice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_ids, int* lens, int* n_gen,
+                                    int* finished, int* out_tokens, int max_new, int min_new, const int* eos,
+                                    int n_eos, int pad_id, hipStream_t stream) {
+  if (nseq <= 0 || V % 8 || ldl % 8 || n_eos < 0 || n_eos > 4) return HWOCR_EINVAL;
+  SelectArgs a{(const bf16*)logits, ldl, V, cur_ids, lens, n_gen, finished, out_tokens, max_new, min_new,
+               {0, 0, 0, 0}, n_eos, pad_id};
+  for (int k = 0; k < n_eos; ++k) a.eos[k] = eos[k];
+  hipLaunchKernelGGL(argmax_advance_kernel, dim3(nseq), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}

@@ -1,0 +1,375 @@
+// bf16 GEMM kernels for the page-read path (gfx950 / MI355X).
+//
+//   out[M][N] = epilogue( X[M][K] . W[N][K]^T )        X, W, out bf16; fp32 accumulation on MFMA
+//
+// W keeps the [out_features][in_features] layout of the checkpoints the reference loads
+// (ocr_agent/tools.py:705-709 -> HF nn.Linear weights), so both operands are K-contiguous and every
+// MFMA fragment is one 16-byte access.  The weight tile is the MFMA A operand and the activation tile
+// the B operand: each lane then owns 4 consecutive output features of one row -> 8-byte stores.
+//
+// Two kernels:
+//   gemm_wide   : 128x128x64 tiles, LDS-DMA staging (global_load_lds_dwordx4), XOR-swizzled LDS image,
+//                 double buffered.  ViT blocks, merger and decoder prefill (MFMA-bound).
+//   gemm_skinny : M <= 128 rows (the reads in flight during decode).  Weights stream HBM -> VGPR once,
+//                 the activation slice is shared through LDS, optional split-K with fp32 partial slabs
+//                 (HBM-bound).
+//
+// Epilogues reproduce the points where the reference's bf16 modules materialise a tensor
+// (HF modeling_qwen2_vl.py:293-301 VisionMlp, :453-466 Qwen2MLP, :442-448 residual adds).
+#include "common.cuh"
+#include "hwocr.h"
+
+namespace {
+
+enum : int {
+  EPI_LINEAR = HWOCR_EPI_LINEAR,        // bf16(acc + bias)
+  EPI_RESIDUAL = HWOCR_EPI_RESIDUAL,    // bf16(bf16(acc + bias) + res)
+  EPI_QUICKGELU = HWOCR_EPI_QUICKGELU,  // x*sigmoid(1.702x), each step rounded like the bf16 module chain
+  EPI_GELU = HWOCR_EPI_GELU,            // exact erf GELU of bf16(acc + bias)
+  EPI_SWIGLU = HWOCR_EPI_SWIGLU,        // rows interleaved [16 gate][16 up]: bf16(bf16(silu(g)) * u)
+  EPI_PARTIAL = HWOCR_EPI_PARTIAL       // fp32 split-K slab (skinny only)
+};
+
+__device__ __forceinline__ float act_quick_gelu(float v) {
+  const float t = rbf(1.702f * v);
+  const float s = rbf(1.0f / (1.0f + __expf(-t)));
+  return v * s;
+}
+__device__ __forceinline__ float act_gelu_erf(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }
+
+// ------------------------------------------------------------------------------------------------
+// gemm_wide
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int WIDE_LDS = 4 * TILE_BYTES; // 2 buffers x (X tile + W tile)
+constexpr int GROUP_M = 8;
+
+struct WideArgs {
+  const bf16* X; const bf16* W; const bf16* bias; const bf16* res; bf16* out;
+  int M, N, K, ldx, ldw, ldo, ldres, tilesM, tilesN;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(WideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+
+  // workgroup -> tile: XCD-contiguous chunks, then GROUP_M row panels swept column-major so that the
+  // workgroups resident on one XCD share a few X panels and W panels in its L2.
+  const int nwg = a.tilesM * a.tilesN;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int per_group = GROUP_M * a.tilesN;
+  const int g = wg / per_group, rem = wg - g * per_group;
+  const int gm = min(GROUP_M, a.tilesM - g * GROUP_M);
+  const int tm = g * GROUP_M + rem % gm, tn = rem / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- LDS-DMA staging plan: wave w fills rows 32w..32w+31 of both tiles, 8 rows (1 KiB) per instruction.
+  // LDS image: row r at r*128 B, 16-byte chunk p holds logical chunk p ^ ((r>>1)&7) (conflict-free ds_read_b128);
+  // the DMA destination is lane-linear, so the permutation is applied to the per-lane SOURCE address.
+  const bf16* xsrc[4];
+  const bf16* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 32 * w + 8 * i + (lane >> 3);
+    const int lc = (lane & 7) ^ ((r >> 1) & 7);
+    xsrc[i] = a.X + (size_t)min(m0 + r, a.M - 1) * a.ldx + lc * 8;
+    wsrc[i] = a.W + (size_t)min(n0 + r, a.N - 1) * a.ldw + lc * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* xb = smem + buf * 2 * TILE_BYTES + (32 * w) * 128;
+    char* wb = xb + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const void*)(xsrc[i] + kt * BK), LDS_PTR(xb + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)(wsrc[i] + kt * BK), LDS_PTR(wb + i * 1024), 16, 0, 0);
+    }
+  };
+
+  // wave grid 2(M) x 2(N): each wave owns a 64(m) x 64(n) block = 4x4 MFMA 16x16 tiles
+  const int wm = w >> 1, wn = w & 1;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int sw = (c >> 1) & 7;  // rows of one fragment are base(16-aligned) + c
+  const int nk = a.K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* xb = smem + cur * 2 * TILE_BYTES;
+    const char* wb = xb + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 wf[4], xf[4];
+      const int choff = ((kk * 4 + q) ^ sw) << 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wf[t] = *(const bf16x8*)(wb + (wn * 64 + t * 16 + c) * 128 + choff);
+        xf[t] = *(const bf16x8*)(xb + (wm * 64 + t * 16 + c) * 128 + choff);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (c,q) of tile (nt,mt) holds out[m = ..+c][n = ..+4q .. 4q+3]
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wm * 64 + mt * 16 + c;
+    if (m >= a.M) continue;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int nt = 0; nt < 4; nt += 2) {
+        const int n = n0 + wn * 64 + nt * 16;  // gate rows n..n+15, up rows n+16..n+31
+        if (n >= a.N) continue;
+        const int j = (n >> 1) + 4 * q;
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gte = rbf(acc[nt][mt][r]);
+          const float up = rbf(acc[nt + 1][mt][r]);
+          o[r] = f2bf(rbf(act_silu(gte)) * up);
+        }
+        *(bf16x4*)(a.out + (size_t)m * a.ldo + j) = o;
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * q;
+        if (n >= a.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[nt][mt][r];
+        if (a.bias) {
+          const bf16x4 b = *(const bf16x4*)(a.bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bf2f(b[r]);
+        }
+        bf16x4 o;
+        if constexpr (EPI == EPI_RESIDUAL) {
+          const bf16x4 rs = *(const bf16x4*)(a.res + (size_t)m * a.ldres + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(v[r]) + bf2f(rs[r]));
+        } else if constexpr (EPI == EPI_QUICKGELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(act_quick_gelu(rbf(v[r])));
+        } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(act_gelu_erf(rbf(v[r])));
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+        }
+        *(bf16x4*)(a.out + (size_t)m * a.ldo + n) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_skinny
+// ------------------------------------------------------------------------------------------------
+constexpr int SK_KC = 256;    // K elements per LDS chunk of the activation slice
+
+struct SkinnyArgs {
+  const bf16* X; const bf16* W; const bf16* bias; void* out;
+  int Bsz, N, K, ldx, ldw, ldo, kslice;
+};
+
+// NT = 16-row weight tiles per wave (2 -> 128 rows per workgroup, 1 -> 64: more workgroups for small N)
+template <int NB, int EPI, int NT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NB*16][256] bf16, chunk p of row r holds p ^ (r&15)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * (64 * NT) + 16 * NT * w;
+  const int ks = blockIdx.y;
+  const int kbeg = ks * a.kslice, kend = min(a.K, kbeg + a.kslice);
+
+  const bf16* wrow[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wrow[t] = a.W + (size_t)min(n0 + 16 * t + c, a.N - 1) * a.ldw + 8 * q;
+
+  f32x4 acc[NT][NB];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kc = kbeg; kc < kend; kc += SK_KC) {
+    const int klen = min(SK_KC, kend - kc);  // multiple of 32
+    const int nks = klen >> 5;
+    // weights for this chunk: straight to VGPRs, all in flight before anything waits
+    bf16x8 wreg[NT][8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        wreg[t][s] = __builtin_nontemporal_load((const bf16x8*)(wrow[t] + min(kc + 32 * s, a.K - 32)));
+    __syncthreads();  // everyone finished reading the previous activation chunk
+    // activation chunk -> LDS by LDS-DMA: one instruction = 2 rows x 512 B
+#pragma unroll
+    for (int i = 0; i < NB * 2; ++i) {
+      const int inst = w * (NB * 2) + i;
+      const int r = 2 * inst + (lane >> 5);
+      const int lc = (lane & 31) ^ (r & 15);
+      const int kk = min(kc + lc * 8, a.K - 8);
+      const bf16* src = a.X + (size_t)min(r, a.Bsz - 1) * a.ldx + kk;
+      __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR(smem + inst * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < nks) {
+        bf16x8 xf[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int r = 16 * b + c;
+          xf[b] = *(const bf16x8*)(smem + r * 512 + (((4 * s + q) ^ (r & 15)) << 4));
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[t][s], xf[b], acc[t][b], 0, 0, 0);
+      }
+    }
+  }
+
+  // lane (c,q): acc[t][b][r] = out[row 16b + c][n0 + 16t + 4q + r]
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int m = 16 * b + c;
+    if (m >= a.Bsz) continue;
+    if constexpr (EPI == EPI_SWIGLU) {
+      static_assert(EPI != EPI_SWIGLU || NT == 2, "gate/up tiles come in pairs");
+      if (n0 < a.N) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gte = rbf(acc[0][b][r]);
+          const float up = rbf(acc[NT - 1][b][r]);
+          o[r] = f2bf(rbf(act_silu(gte)) * up);
+        }
+        *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + (n0 >> 1) + 4 * q) = o;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = n0 + 16 * t + 4 * q;
+        if (n >= a.N) continue;
+        if constexpr (EPI == EPI_PARTIAL) {
+          float* dst = (float*)a.out + ((size_t)ks * a.Bsz + m) * a.ldo + n;
+          *(f32x4*)dst = acc[t][b];
+        } else {
+          bf16x4 o;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[t][b][r];
+          if (a.bias) {
+            const bf16x4 bb = *(const bf16x4*)(a.bias + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bf2f(bb[r]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+          *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + n) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int NB>
+int launch_skinny(const SkinnyArgs& a, int epi, int splitk, hipStream_t st) {
+  // small N: 64-row workgroups so that the grid still covers the chip
+  const bool narrow = epi != EPI_SWIGLU && ((a.N + 127) / 128) * splitk < 256;
+  const int rows = narrow ? 64 : 128;
+  dim3 grid((a.N + rows - 1) / rows, splitk), block(256);
+  const size_t lds = (size_t)NB * 16 * 512;
+  switch (epi) {
+    case EPI_LINEAR:
+      if (narrow) hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI_LINEAR, 1>), grid, block, lds, st, a);
+      else hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI_LINEAR, 2>), grid, block, lds, st, a);
+      break;
+    case EPI_SWIGLU: hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI_SWIGLU, 2>), grid, block, lds, st, a); break;
+    case EPI_PARTIAL:
+      if (narrow) hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI_PARTIAL, 1>), grid, block, lds, st, a);
+      else hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI_PARTIAL, 2>), grid, block, lds, st, a);
+      break;
+    default: return HWOCR_EINVAL;
+  }
+  return hwocr_launch_status();
+}
+
+}  // namespace
+
+extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, const void* res, void* out,
+                               int M, int N, int K, int ldx, int ldw, int ldo, int ldres, int epi,
+                               hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 8) != 0 || (ldx % 8) || (ldw % 8) || (ldo % 4))
+    return HWOCR_EINVAL;
+  if (epi == EPI_SWIGLU && ((N % 32) != 0 || bias)) return HWOCR_EINVAL;
+  if (epi == EPI_RESIDUAL && (!res || (ldres % 4))) return HWOCR_EINVAL;
+  WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)out,
+             M, N, K, ldx, ldw, ldo, ldres, (M + BM - 1) / BM, (N + BN - 1) / BN};
+  dim3 grid(a.tilesM * a.tilesN), block(256);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_LINEAR>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
+    hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
+    hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_QUICKGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
+    hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
+    hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
+    attr_done = true;
+  }
+  switch (epi) {
+    case EPI_LINEAR: hipLaunchKernelGGL(gemm_wide_kernel<EPI_LINEAR>, grid, block, WIDE_LDS, stream, a); break;
+    case EPI_RESIDUAL: hipLaunchKernelGGL(gemm_wide_kernel<EPI_RESIDUAL>, grid, block, WIDE_LDS, stream, a); break;
+    case EPI_QUICKGELU: hipLaunchKernelGGL(gemm_wide_kernel<EPI_QUICKGELU>, grid, block, WIDE_LDS, stream, a); break;
+    case EPI_GELU: hipLaunchKernelGGL(gemm_wide_kernel<EPI_GELU>, grid, block, WIDE_LDS, stream, a); break;
+    case EPI_SWIGLU: hipLaunchKernelGGL(gemm_wide_kernel<EPI_SWIGLU>, grid, block, WIDE_LDS, stream, a); break;
+    default: return HWOCR_EINVAL;
+  }
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out, int Bsz, int N,
+                                 int K, int ldx, int ldw, int ldo, int epi, int splitk, hipStream_t stream) {
+  if (Bsz <= 0 || Bsz > 128 || N <= 0 || K <= 0 || (K % 32) || (N % 16) || (epi == EPI_SWIGLU && (N % 32)) || (ldx % 8) || (ldw % 8) || (ldo % 4) ||
+      splitk < 1)
+    return HWOCR_EINVAL;
+  if (epi != EPI_PARTIAL && splitk != 1) return HWOCR_EINVAL;
+  if (epi == EPI_SWIGLU && bias) return HWOCR_EINVAL;
+  // K slice per split: whole 256-element chunks
+  int chunks = (K + SK_KC - 1) / SK_KC;
+  int per = (chunks + splitk - 1) / splitk;
+  SkinnyArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, out, Bsz, N, K, ldx, ldw, ldo, per * SK_KC};
+  if ((splitk - 1) * a.kslice >= K) return HWOCR_EINVAL;  // an empty slice would leave its slab unwritten
+  const int nb = (Bsz + 15) / 16;
+  switch (nb) {
+    case 1: return launch_skinny<1>(a, epi, splitk, stream);
+    case 2: return launch_skinny<2>(a, epi, splitk, stream);
+    case 3: return launch_skinny<3>(a, epi, splitk, stream);
+    case 4: return launch_skinny<4>(a, epi, splitk, stream);
+    case 5: case 6: return launch_skinny<6>(a, epi, splitk, stream);
+    default: return launch_skinny<8>(a, epi, splitk, stream);
+  }
+}

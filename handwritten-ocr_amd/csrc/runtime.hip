@@ -1,0 +1,205 @@
+// Model-level launch sequences: what `model.generate` (ocr_agent/tools.py:764-765) expands to for the
+// Qwen2-VL family, expressed as kernel launches on one HIP stream with caller-owned buffers.
+//   hwocr_vit_forward  <- Qwen2VisionTransformerPretrainedModel.forward (HF modeling_qwen2_vl.py:700-729)
+//   hwocr_prefill      <- Qwen2VLModel.forward splice + Qwen2VLTextModel.forward + lm_head (… :790-872, :1383-1387)
+//   hwocr_decode_step  <- one iteration of GenerationMixin._sample's while loop (HF generation/utils.py:2876-2941)
+// The decode step touches only device state (token ids, lengths, stop flags live in HBM), so it can be captured
+// once into a HIP graph and replayed for every generated token without a host round trip.
+#include "common.cuh"
+#include "hwocr.h"
+#include <vector>
+
+#define CHECK(call)                \
+  do {                             \
+    const int rc_ = (call);        \
+    if (rc_ != HWOCR_OK) return rc_; \
+  } while (0)
+
+namespace {
+constexpr int HD = 128;  // decoder head_dim
+inline bf16* B(void* p) { return (bf16*)p; }
+inline const bf16* B(const void* p) { return (const bf16*)p; }
+inline int pick_splitk(int K, int N, int want_wgs) {
+  const int chunks = (K + 255) / 256;
+  const int tiles = (N + 63) / 64;
+  int s = (want_wgs + tiles - 1) / tiles;
+  if (s < 1) s = 1;
+  if (s > chunks) s = chunks;
+  // every slice must own at least one chunk
+  const int per = (chunks + s - 1) / s;
+  s = (chunks + per - 1) / per;
+  return s;
+}
+}  // namespace
+
+extern "C" int hwocr_abi_version(void) { return 1; }
+
+extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, const void* images, int nimg, int H,
+                                 int W, int rows_per_img_ld, const int* pos_h, const int* pos_w,
+                                 const int* seg_lens, void* out, hipStream_t st) {
+  if (!m || !ws || nimg <= 0 || rows_per_img_ld % 64) return HWOCR_EINVAL;
+  const int D = m->dim, hd = D / m->heads, rows = nimg * rows_per_img_ld;
+  const int P = (H / m->patch) * (W / m->patch);
+  const int mm = m->merge * m->merge;
+  CHECK(hwocr_patchify(images, m->pixel_lut, ws->patches, nimg, H, W, m->patch, m->merge, m->tps, m->kpad,
+                       rows_per_img_ld, st));
+  CHECK(hwocr_gemm_wide(ws->patches, m->patch_w, nullptr, nullptr, ws->x, rows, D, m->kpad, m->kpad, m->kpad, D, 0,
+                        HWOCR_EPI_LINEAR, st));
+  const float scale = 1.0f / sqrtf((float)hd);
+  for (int l = 0; l < m->depth; ++l) {
+    const hwocr_vit_block& b = m->blocks[l];
+    CHECK(hwocr_layernorm(ws->x, b.ln1_w, b.ln1_b, ws->xn, rows, D, D, D, m->eps, st));
+    CHECK(hwocr_gemm_wide(ws->xn, b.qkv_w, b.qkv_b, nullptr, ws->qkv, rows, 3 * D, D, D, D, 3 * D, 0,
+                          HWOCR_EPI_LINEAR, st));
+    CHECK(hwocr_vit_rope_split(ws->qkv, ws->q, ws->k, ws->vt, pos_h, pos_w, m->rope_cos, m->rope_sin, rows, rows,
+                               m->heads, hd, st));
+    CHECK(hwocr_attn_prefill(ws->q, ws->k, ws->vt, ws->attn, seg_lens, nimg, m->heads, 1, hd, P, 0,
+                             (long)rows_per_img_ld * hd, (long)rows * hd, hd,   // Q [head][rows][hd]
+                             (long)rows_per_img_ld * hd, (long)rows * hd, hd,   // K
+                             rows_per_img_ld, (long)hd * rows, rows,            // V^T [head][hd][rows]
+                             (long)rows_per_img_ld * D, D, scale, st));
+    CHECK(hwocr_gemm_wide(ws->attn, b.proj_w, b.proj_b, ws->x, ws->x, rows, D, D, D, D, D, D, HWOCR_EPI_RESIDUAL, st));
+    CHECK(hwocr_layernorm(ws->x, b.ln2_w, b.ln2_b, ws->xn, rows, D, D, D, m->eps, st));
+    CHECK(hwocr_gemm_wide(ws->xn, b.fc1_w, b.fc1_b, nullptr, ws->mlp, rows, m->mlp_dim, D, D, D, m->mlp_dim, 0,
+                          HWOCR_EPI_QUICKGELU, st));
+    CHECK(hwocr_gemm_wide(ws->mlp, b.fc2_w, b.fc2_b, ws->x, ws->x, rows, D, m->mlp_dim, m->mlp_dim, m->mlp_dim, D, D,
+                          HWOCR_EPI_RESIDUAL, st));
+  }
+  // patch merger: LN -> view(-1, merge^2 * D) -> Linear -> GELU -> Linear
+  CHECK(hwocr_layernorm(ws->x, m->merger_ln_w, m->merger_ln_b, ws->xn, rows, D, D, D, m->eps, st));
+  const int mrows = rows / mm, MD = mm * D;
+  CHECK(hwocr_gemm_wide(ws->xn, m->merger_fc1_w, m->merger_fc1_b, nullptr, ws->merge_mid, mrows, MD, MD, MD, MD, MD, 0,
+                        HWOCR_EPI_GELU, st));
+  CHECK(hwocr_gemm_wide(ws->merge_mid, m->merger_fc2_w, m->merger_fc2_b, nullptr, out, mrows, m->out_dim, MD, MD, MD,
+                        m->out_dim, 0, HWOCR_EPI_LINEAR, st));
+  return HWOCR_OK;
+}
+
+extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
+                             const hwocr_gen_state* gs, const int* ids, const int* img_row, const void* img_embeds,
+                             const int* pos3, const int* seq_lens, const int* last_rows, int nseq, int rows_per_seq,
+                             int seq0, int max_len, hipStream_t st) {
+  if (!m || !ws || !kv || !gs || nseq <= 0 || rows_per_seq % 64 || rows_per_seq > kv->ctx ||
+      seq0 + nseq > kv->nseq_max || nseq > 128)
+    return HWOCR_EINVAL;
+  const int rows = nseq * rows_per_seq, Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD;
+  const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
+  const float scale = 1.0f / sqrtf((float)HD);
+  CHECK(hwocr_embed_splice(ids, img_row, m->embed, img_embeds, ws->h, rows, Hd, 1.0f, st));
+  for (int l = 0; l < m->layers; ++l) {
+    const hwocr_dec_layer& L = m->L[l];
+    bf16* Kc = B(kv->k) + l * k_layer + seq0 * k_seq;
+    bf16* Vc = B(kv->vt) + l * k_layer + seq0 * k_seq;
+    CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.in_norm_w, ws->hn, Hd, nullptr, rows, Hd, m->eps,
+                            0, st));
+    CHECK(hwocr_gemm_wide(ws->hn, L.qkv_w, L.qkv_b, nullptr, ws->qkv, rows, QW, Hd, Hd, Hd, QW, 0, HWOCR_EPI_LINEAR,
+                          st));
+    CHECK(hwocr_mrope_kv_prefill(ws->qkv, ws->q, Kc, Vc, pos3, m->rope_cos, m->rope_sin, rows, rows_per_seq, m->Hq,
+                                 m->Hkv, m->sec0, m->sec1, k_seq, k_head, k_seq, k_head, kv->ctx, st));
+    CHECK(hwocr_attn_prefill(ws->q, Kc, Vc, ws->attn, seq_lens, nseq, m->Hq, m->Hq / m->Hkv, HD, max_len, 1,
+                             (long)rows_per_seq * m->Hq * HD, HD, (long)m->Hq * HD,  // Q [row][Hq][128]
+                             k_seq, k_head, HD, k_seq, k_head, kv->ctx,
+                             (long)rows_per_seq * m->Hq * HD, (long)m->Hq * HD, scale, st));
+    CHECK(hwocr_gemm_wide(ws->attn, L.o_w, nullptr, ws->h, ws->h, rows, Hd, m->Hq * HD, m->Hq * HD, m->Hq * HD, Hd, Hd,
+                          HWOCR_EPI_RESIDUAL, st));
+    CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd, nullptr, rows, Hd,
+                            m->eps, 0, st));
+    CHECK(hwocr_gemm_wide(ws->hn, L.gate_up_w, nullptr, nullptr, ws->act, rows, 2 * m->inter, Hd, Hd, Hd, m->inter, 0,
+                          HWOCR_EPI_SWIGLU, st));
+    CHECK(hwocr_gemm_wide(ws->act, L.down_w, nullptr, ws->h, ws->h, rows, Hd, m->inter, m->inter, m->inter, Hd, Hd,
+                          HWOCR_EPI_RESIDUAL, st));
+  }
+  // final norm on the last prompt token of every read -> LM head -> first generated token
+  CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->final_norm_w, ws->hn, Hd, last_rows, nseq, Hd,
+                          m->eps, 0, st));
+  CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd, Hd, m->vocab,
+                          HWOCR_EPI_LINEAR, 1, st));
+  CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids + seq0, gs->lens + seq0,
+                             gs->n_gen + seq0, gs->finished + seq0, gs->out_tokens + (long)seq0 * gs->max_new,
+                             gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, st));
+  return HWOCR_OK;
+}
+
+extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
+                                 const hwocr_gen_state* gs, int nseq, int attn_splits, hipStream_t st) {
+  if (!m || !ws || !kv || !gs || nseq <= 0 || nseq > 128 || nseq > kv->nseq_max || attn_splits < 1)
+    return HWOCR_EINVAL;
+  const int Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
+  const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
+  const float scale = 1.0f / sqrtf((float)HD);
+  const int s_qkv = pick_splitk(Hd, QW, 256), s_o = pick_splitk(OW, Hd, 256), s_d = pick_splitk(m->inter, Hd, 512);
+  CHECK(hwocr_embed_splice(gs->cur_ids, nullptr, m->embed, nullptr, ws->h, nseq, Hd, 1.0f, st));
+  CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->L[0].in_norm_w, ws->hn, Hd, nullptr, nseq, Hd,
+                          m->eps, 0, st));
+  for (int l = 0; l < m->layers; ++l) {
+    const hwocr_dec_layer& L = m->L[l];
+    bf16* Kc = B(kv->k) + l * k_layer;
+    bf16* Vc = B(kv->vt) + l * k_layer;
+    CHECK(hwocr_gemm_skinny(ws->hn, L.qkv_w, nullptr, ws->slabs, nseq, QW, Hd, Hd, Hd, QW, HWOCR_EPI_PARTIAL, s_qkv, st));
+    CHECK(hwocr_decode_qkv_finish(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, ws->q, Kc, Vc, gs->lens, gs->rope_delta,
+                                  m->rope_cos, m->rope_sin, nseq, m->Hq, m->Hkv, k_seq, k_head, k_seq, k_head,
+                                  kv->ctx, st));
+    CHECK(hwocr_attn_decode(ws->q, Kc, Vc, gs->lens, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv,
+                            attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, st));
+    CHECK(hwocr_gemm_skinny(ws->attn, L.o_w, nullptr, ws->slabs, nseq, Hd, OW, OW, OW, Hd, HWOCR_EPI_PARTIAL, s_o, st));
+    CHECK(hwocr_add_rmsnorm(ws->slabs, s_o, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd,
+                            nullptr, nseq, Hd, m->eps, 0, st));
+    CHECK(hwocr_gemm_skinny(ws->hn, L.gate_up_w, nullptr, ws->act, nseq, 2 * m->inter, Hd, Hd, Hd, m->inter,
+                            HWOCR_EPI_SWIGLU, 1, st));
+    CHECK(hwocr_gemm_skinny(ws->act, L.down_w, nullptr, ws->slabs, nseq, Hd, m->inter, m->inter, m->inter, Hd,
+                            HWOCR_EPI_PARTIAL, s_d, st));
+    const void* next_norm = (l + 1 < m->layers) ? m->L[l + 1].in_norm_w : m->final_norm_w;
+    CHECK(hwocr_add_rmsnorm(ws->slabs, s_d, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, next_norm, ws->hn, Hd, nullptr,
+                            nseq, Hd, m->eps, 0, st));
+  }
+  CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd, Hd, m->vocab,
+                          HWOCR_EPI_LINEAR, 1, st));
+  CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished,
+                             gs->out_tokens, gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, st));
+  return HWOCR_OK;
+}
+
+struct DecodeGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int hwocr_decode_graph_create(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
+                                         const hwocr_gen_state* gs, int nseq, int attn_splits, void** graph_out) {
+  if (!graph_out) return HWOCR_EINVAL;
+  hipStream_t cap;
+  if (hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) return HWOCR_ELAUNCH;
+  DecodeGraph* g = new DecodeGraph();
+  int rc = HWOCR_OK;
+  if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = HWOCR_ELAUNCH;
+  if (rc == HWOCR_OK) {
+    rc = hwocr_decode_step(m, ws, kv, gs, nseq, attn_splits, cap);
+    if (hipStreamEndCapture(cap, &g->graph) != hipSuccess) rc = rc ? rc : HWOCR_ELAUNCH;
+  }
+  if (rc == HWOCR_OK && hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) rc = HWOCR_ELAUNCH;
+  (void)hipStreamDestroy(cap);
+  if (rc != HWOCR_OK) {
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return rc;
+  }
+  *graph_out = g;
+  return HWOCR_OK;
+}
+
+extern "C" int hwocr_decode_graph_launch(void* graph, int n, hipStream_t st) {
+  DecodeGraph* g = (DecodeGraph*)graph;
+  if (!g || !g->exec || n < 0) return HWOCR_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (hipGraphLaunch(g->exec, st) != hipSuccess) return HWOCR_ELAUNCH;
+  return HWOCR_OK;
+}
+
+extern "C" int hwocr_decode_graph_destroy(void* graph) {
+  DecodeGraph* g = (DecodeGraph*)graph;
+  if (!g) return HWOCR_EINVAL;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+  return HWOCR_OK;
+}

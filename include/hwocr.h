@@ -1,0 +1,181 @@
+/*
+ * hwocr.h — C ABI of the MI355X-native page-read engine (libhwocr_hip.so) and of the native text
+ * kernels (libhwocr_text.so).
+ *
+ * The reference (marwanbounassif/handwritten-ocr) has no native boundary: its hot path is the Python call
+ *   ocr_agent/tools.py:728  run_ocr(image_path, params) -> str
+ * which drives HF transformers (processor -> model.generate -> decode, tools.py:756-769), plus the pure-Python
+ * string DP of compare_versions / merge_versions (tools.py:326-493).  This header is the seam a maintainer binds
+ * instead (ctypes stub in INTEGRATION.md): plain device pointers, sizes and a HIP stream; no torch types;
+ * every function returns HWOCR_OK (0) or an error code and never throws; no hidden allocation — the caller owns
+ * every buffer, including workspaces.
+ *
+ * All device tensors are bf16 unless stated.  "rows" are tokens (vision patches or prompt positions) or,
+ * during decode, the reads in flight (one row per read).
+ */
+#ifndef HWOCR_H
+#define HWOCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
+
+#define HWOCR_OK 0
+#define HWOCR_EINVAL 1
+#define HWOCR_ELAUNCH 2
+
+/* GEMM epilogues (see csrc/gemm.hip) */
+#define HWOCR_EPI_LINEAR 0
+#define HWOCR_EPI_RESIDUAL 1
+#define HWOCR_EPI_QUICKGELU 2
+#define HWOCR_EPI_GELU 3
+#define HWOCR_EPI_SWIGLU 4
+#define HWOCR_EPI_PARTIAL 5
+
+int hwocr_abi_version(void);
+
+/* ---- single operators (each replaces the ATen op reached from the cited HF module) ------------------------- */
+
+/* out[M][N] = epi(X[M][K] . W[N][K]^T); replaces nn.Linear / Conv3d-as-GEMM (HF modeling_qwen2_vl.py:266-274,
+ * :293-301, :349-350, :453-466, :501-504).  K % 64 == 0, N % 8 == 0. */
+int hwocr_gemm_wide(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
+                    int ldx, int ldw, int ldo, int ldres, int epi, hwocr_stream_t stream);
+
+/* Same contraction for <= 128 rows (decode).  epi PARTIAL writes fp32 slabs out[splitk][Bsz][ldo]. */
+int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out, int Bsz, int N, int K, int ldx,
+                      int ldw, int ldo, int epi, int splitk, hwocr_stream_t stream);
+
+/* Whole-segment attention (HF modeling_qwen2_vl.py:375-418 vision, :553-569 decoder prefill).
+ * Element strides; V is passed transposed (VT[d][key]); every segment's key range must be readable up to the
+ * next multiple of 64. */
+int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, void* O, const int* lens, int nseg, int heads,
+                       int group, int head_dim, int max_len, int causal, long q_seg, long q_head, long q_row,
+                       long k_seg, long k_head, long k_row, long v_seg, long v_head, long v_row, long o_seg,
+                       long o_row, float scale, hwocr_stream_t stream);
+
+/* One query token per read against its KV cache (HF modeling_qwen2_vl.py:553-569 with q_len == 1). head_dim 128. */
+int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out, float* part_o,
+                      float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head, long v_seq,
+                      long v_head, long v_row, float scale, hwocr_stream_t stream);
+
+/* uint8 HWC resized pages -> bf16 patch rows (HF image_processing_pil_qwen2_vl.py:152-187, :226-229). */
+int hwocr_patchify(const void* img, const void* lut, void* out, int nimg, int H, int W, int patch, int merge,
+                   int tps, int kpad, int rows_per_img_ld, hwocr_stream_t stream);
+
+int hwocr_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int D, int ldx, int ldo,
+                    float eps, hwocr_stream_t stream);
+
+/* h <- bf16(bf16(sum slabs + bias) + h) (if nslab > 0); out <- RMSNorm(h) * w (if out != NULL). */
+int hwocr_add_rmsnorm(const float* slabs, int nslab, long slab_stride, int ld_slab, const void* bias, void* h,
+                      int ldh, const void* w, void* out, int ldo, const int* row_index, int rows, int D, float eps,
+                      int gemma, hwocr_stream_t stream);
+
+int hwocr_vit_rope_split(const void* qkv, void* Q, void* K, void* VT, const int* pos_h, const int* pos_w,
+                         const float* cos_tab, const float* sin_tab, int tokens, int tok_ld, int heads, int hd,
+                         hwocr_stream_t stream);
+
+/* rows are laid out [nseq][rows_per_seq]; row r belongs to read r / rows_per_seq (K, VT point at the first read's
+ * cache), cache slot r % rows_per_seq */
+int hwocr_mrope_kv_prefill(const void* qkv, void* Q, void* K, void* VT, const int* pos, const void* cos_tab,
+                           const void* sin_tab, int rows, int rows_per_seq, int Hq, int Hkv, int sec0, int sec1,
+                           long k_seq, long k_head, long v_seq, long v_head, long v_row, hwocr_stream_t stream);
+
+int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_stride, const void* bias, void* Q, void* K,
+                            void* VT, const int* lens, const int* rope_delta, const void* cos_tab,
+                            const void* sin_tab, int nseq, int Hq, int Hkv, long k_seq, long k_head, long v_seq,
+                            long v_head, long v_row, hwocr_stream_t stream);
+
+int hwocr_embed_splice(const int* ids, const int* img_row, const void* table, const void* img, void* out, int rows,
+                       int D, float scale, hwocr_stream_t stream);
+
+int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_ids, int* lens, int* n_gen,
+                         int* finished, int* out_tokens, int max_new, int min_new, const int* eos, int n_eos,
+                         int pad_id, hwocr_stream_t stream);
+
+/* ---- model-level entry points (what run_ocr's model.generate expands to) ----------------------------------- */
+
+typedef struct {
+  const void *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} hwocr_vit_block;
+
+typedef struct {
+  int depth, dim, heads, mlp_dim, patch, merge, tps, kpad, out_dim;
+  float eps;
+  const void* patch_w;            /* [dim][kpad], zero beyond 3*tps*patch^2 */
+  const hwocr_vit_block* blocks;  /* host array[depth] of device pointers */
+  const void *merger_ln_w, *merger_ln_b, *merger_fc1_w, *merger_fc1_b, *merger_fc2_w, *merger_fc2_b;
+  const float *rope_cos, *rope_sin; /* fp32 [maxpos][head_dim/4] */
+  const void* pixel_lut;            /* bf16 [3][256] */
+} hwocr_vit;
+
+typedef struct { /* all device buffers, rows = nimg * rows_per_img_ld */
+  void *patches, *x, *xn, *qkv, *q, *k, *vt, *attn, *mlp, *merge_mid;
+} hwocr_vit_ws;
+
+/* images: uint8 [nimg][H][W][3] already resized to multiples of patch*merge; out: [rows/merge^2][out_dim] */
+int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, const void* images, int nimg, int H, int W,
+                      int rows_per_img_ld, const int* pos_h, const int* pos_w, const int* seg_lens, void* out,
+                      hwocr_stream_t stream);
+
+typedef struct {
+  const void *in_norm_w, *qkv_w, *qkv_b, *o_w, *post_norm_w, *gate_up_w, *down_w;
+} hwocr_dec_layer;
+
+typedef struct {
+  int layers, hidden, Hq, Hkv, inter, vocab, sec0, sec1;
+  float eps;
+  const void* embed;        /* [vocab][hidden] */
+  const void* lm_head;      /* [vocab][hidden] (may alias embed) */
+  const void* final_norm_w;
+  const hwocr_dec_layer* L; /* host array[layers] */
+  const void *rope_cos, *rope_sin; /* bf16 [maxpos][64] */
+} hwocr_decoder;
+
+typedef struct { /* KV cache: K [layer][seq][Hkv][ctx][128], VT [layer][seq][Hkv][128][ctx] */
+  void* k; void* vt; int nseq_max, ctx;
+} hwocr_kv;
+
+typedef struct {
+  void *h, *hn, *qkv, *q, *attn, *act;   /* bf16 [rows][...] */
+  float *slabs;                           /* fp32 split-K slabs (decode) */
+  float *part_o, *part_ml;                /* decode attention partials */
+  void *logits;                           /* bf16 [nseq][vocab] */
+} hwocr_dec_ws;
+
+typedef struct {
+  int *cur_ids, *lens, *n_gen, *finished, *out_tokens, *rope_delta; /* device int32 */
+  int max_new, min_new, n_eos, pad_id;
+  int eos[4];
+} hwocr_gen_state;
+
+/* prefill nseq reads laid out [nseq][rows_per_seq]; writes KV for reads seq0.. and the first generated token */
+int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv, const hwocr_gen_state* st,
+                  const int* ids, const int* img_row, const void* img_embeds, const int* pos3, const int* seq_lens,
+                  const int* last_rows, int nseq, int rows_per_seq, int seq0, int max_len, hwocr_stream_t stream);
+
+/* one greedy token for every read in flight (reads 0..nseq-1 of the cache) */
+int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv, const hwocr_gen_state* st,
+                      int nseq, int attn_splits, hwocr_stream_t stream);
+
+/* capture one decode step into a HIP graph; replay it n times back-to-back on `stream` */
+int hwocr_decode_graph_create(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
+                              const hwocr_gen_state* st, int nseq, int attn_splits, void** graph_out);
+int hwocr_decode_graph_launch(void* graph, int n, hwocr_stream_t stream);
+int hwocr_decode_graph_destroy(void* graph);
+
+/* ---- native text kernels (libhwocr_text.so, host C++) ------------------------------------------------------- */
+
+/* unit-cost edit distance over code points / word ids; replaces tools.py:69-100 */
+int64_t hwocr_levenshtein_u32(const uint32_t* a, int64_t n, const uint32_t* b, int64_t m);
+/* LCS alignment of `words` to `backbone` over case-folded word ids; out[i] = index into words or -1.
+ * Replaces tools.py:465-493 (same tie-breaking in the backtrack). */
+int hwocr_lcs_align_u32(const uint32_t* backbone, int64_t n, const uint32_t* words, int64_t m, int32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,414 @@
+"""Operator-level parity on the MI355X: each HIP kernel, called through the C ABI, against the fp32 restatement of
+the op it replaces (same bf16 inputs, fp32 math, the reference's rounding points).  Tolerances are in bf16 ulps of
+the output and are written at each assert."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests._gpu_util import DEV, assert_close_bf16, lib, p, randbf, rbf, st  # noqa: E402
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _epilogue_ref(acc, bias, res, epi):
+    v = acc + (bias.float() if bias is not None else 0.0)
+    if epi == 0:
+        return v
+    if epi == 1:
+        return rbf(v) + res.float()
+    if epi == 2:
+        x = rbf(v)
+        t = rbf(1.702 * x)
+        return x * rbf(torch.sigmoid(t))
+    if epi == 3:
+        x = rbf(v)
+        return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    raise AssertionError
+
+
+def _swiglu_ref(acc):
+    # weight rows interleaved [16 gate][16 up]
+    M, N = acc.shape
+    a = acc.view(M, N // 32, 2, 16)
+    g, u = rbf(a[:, :, 0, :]), rbf(a[:, :, 1, :])
+    return (rbf(torch.nn.functional.silu(g)) * u).reshape(M, N // 2)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1000, 384, 1216), (257, 1536, 1536)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_wide(M, N, K, epi):
+    x = randbf(M, K, scale=1.0, seed=1)
+    w = randbf(N, K, scale=K ** -0.5, seed=2)
+    bias = randbf(N, scale=0.5, seed=3)
+    res = randbf(M, N, seed=4)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rc = lib().hwocr_gemm_wide(p(x), p(w), p(bias), p(res) if epi == 1 else None, p(out), M, N, K, K, K, N, N, epi, st())
+    assert rc == 0
+    sync()
+    acc = x.float() @ w.float().t()
+    want = _epilogue_ref(acc, bias, res, epi)
+    # 2 bf16 ulps of the largest rounded intermediate (bf16(acc+bias), the residual) + fp32 accumulation-order noise
+    mag = (acc + bias.float()).abs() + (res.float().abs() if epi == 1 else 0.0)
+    assert_close_bf16(out, want, ulps=2.0, atol=2e-3, what=f"gemm_wide epi={epi}", mag=mag)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (129, 17920 // 10, 1536)])
+def test_gemm_wide_swiglu(M, N, K):
+    N = (N // 32) * 32
+    x = randbf(M, K, seed=5)
+    w = randbf(N, K, scale=K ** -0.5, seed=6)
+    out = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rc = lib().hwocr_gemm_wide(p(x), p(w), None, None, p(out), M, N, K, K, K, N // 2, 0, 4, st())
+    assert rc == 0
+    sync()
+    assert_close_bf16(out, _swiglu_ref(x.float() @ w.float().t()), ulps=3.0, atol=2e-3, what="gemm_wide swiglu")
+
+
+def test_gemm_wide_rejects_bad_shapes():
+    x = randbf(64, 72)
+    assert lib().hwocr_gemm_wide(p(x), p(x), None, None, p(x), 64, 64, 72, 72, 72, 64, 0, 0, st()) == 1  # K % 64
+
+
+@pytest.mark.parametrize("B", [1, 7, 16, 48, 96, 128])
+@pytest.mark.parametrize("N,K", [(96, 64), (2048, 1536), (1536, 2304)])
+def test_gemm_skinny_linear_and_partial(B, N, K):
+    x = randbf(B, K, seed=7)
+    w = randbf(N, K, scale=K ** -0.5, seed=8)
+    bias = randbf(N, scale=0.5, seed=9)
+    acc = x.float() @ w.float().t()
+    out = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert lib().hwocr_gemm_skinny(p(x), p(w), p(bias), p(out), B, N, K, K, K, N, 0, 1, st()) == 0
+    sync()
+    assert_close_bf16(out, acc + bias.float(), ulps=2.0, atol=2e-3, what="skinny linear")
+    chunks = (K + 255) // 256
+    for splitk in sorted({1, min(3, chunks), chunks}):
+        per = (chunks + splitk - 1) // splitk
+        if (splitk - 1) * per * 256 >= K:
+            continue
+        slabs = torch.full((splitk, B, N), float("nan"), dtype=torch.float32, device=DEV)
+        assert lib().hwocr_gemm_skinny(p(x), p(w), None, p(slabs), B, N, K, K, K, N, 5, splitk, st()) == 0
+        sync()
+        got = slabs.sum(0)
+        assert torch.allclose(got, acc, rtol=1e-4, atol=2e-3), f"partial splitk={splitk}: {(got-acc).abs().max()}"
+
+
+@pytest.mark.parametrize("B", [3, 48, 96])
+def test_gemm_skinny_swiglu(B):
+    N, K = 2 * 1792, 1536
+    x = randbf(B, K, seed=10)
+    w = randbf(N, K, scale=K ** -0.5, seed=11)
+    out = torch.full((B, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert lib().hwocr_gemm_skinny(p(x), p(w), None, p(out), B, N, K, K, K, N // 2, 4, 1, st()) == 0
+    sync()
+    assert_close_bf16(out, _swiglu_ref(x.float() @ w.float().t()), ulps=3.0, atol=2e-3, what="skinny swiglu")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _sdpa_ref(q, k, v, causal, scale):
+    # q [Hq, L, d], k/v [Hkv, L, d] (fp32); returns [L, Hq, d]
+    Hq, Lq, d = q.shape
+    g = Hq // k.shape[0]
+    k = k.repeat_interleave(g, 0)
+    v = v.repeat_interleave(g, 0)
+    s = (q @ k.transpose(1, 2)) * scale
+    if causal:
+        s = s + torch.full((Lq, Lq), float("-inf"), device=q.device).triu(1)
+    return (torch.softmax(s, -1) @ v).permute(1, 0, 2)
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,causal", [(80, 4, 4, False), (128, 6, 2, True), (32, 2, 2, False),
+                                               (64, 2, 1, True), (128, 2, 2, False)])
+def test_attn_prefill(hd, Hq, Hkv, causal):
+    lens = [300, 64, 37, 129]
+    nseg, Lp = len(lens), 320  # per-segment stride, multiple of 64
+    q = randbf(nseg, Lp, Hq, hd, seed=12)
+    k = randbf(nseg, Hkv, Lp, hd, seed=13)
+    v = randbf(nseg, Hkv, Lp, hd, seed=14)
+    vt = v.transpose(2, 3).contiguous()  # [nseg][Hkv][hd][Lp]
+    # poison the key padding: it must never reach the output
+    for s, n in enumerate(lens):
+        vt[s, :, :, n:] = float("nan")
+        k[s, :, n:, :] = 1e4
+    out = torch.zeros(nseg, Lp, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    scale = hd ** -0.5
+    rc = lib().hwocr_attn_prefill(p(q), p(k), p(vt), p(out), p(lens_d), nseg, Hq, Hq // Hkv, hd, max(lens), int(causal),
+                                  Lp * Hq * hd, hd, Hq * hd, Hkv * Lp * hd, Lp * hd, hd,
+                                  Hkv * hd * Lp, hd * Lp, Lp, Lp * Hq * hd, Hq * hd, scale, st())
+    assert rc == 0
+    sync()
+    for s, n in enumerate(lens):
+        want = _sdpa_ref(q[s, :n].float().permute(1, 0, 2), k[s, :, :n].float(), v[s, :, :n].float(), causal, scale)
+        got = out[s, :n].view(n, Hq, hd)
+        # P is rounded to bf16 before the PV product (as the reference's bf16 attention does): ~2^-8 relative on
+        # each of the weights -> allow 4 output ulps + 4e-3 absolute
+        assert_close_bf16(got, want, ulps=4.0, atol=4e-3, what=f"attn_prefill seg {s}")
+    assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("nsplit", [1, 4])
+def test_attn_decode(nsplit):
+    Hq, Hkv, hd, ctx = 12, 2, 128, 640
+    lens = [1, 63, 64, 65, 500, 640]
+    B = len(lens)
+    q = randbf(B, Hq, hd, seed=15)
+    k = randbf(B, Hkv, ctx, hd, seed=16)
+    v = randbf(B, Hkv, ctx, hd, seed=17)
+    vt = v.transpose(2, 3).contiguous()
+    for b, n in enumerate(lens):
+        vt[b, :, :, n:] = float("nan")
+        k[b, :, n:, :] = 1e4
+    out = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    G = Hq // Hkv
+    part_o = torch.zeros(B * Hkv * nsplit * G * hd, dtype=torch.float32, device=DEV)
+    part_ml = torch.zeros(B * Hkv * nsplit * G * 2, dtype=torch.float32, device=DEV)
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    rc = lib().hwocr_attn_decode(p(q), p(k), p(vt), p(lens_d), p(out), p(part_o), p(part_ml), B, Hq, Hkv, nsplit,
+                                 Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, st())
+    assert rc == 0
+    sync()
+    for b, n in enumerate(lens):
+        qq = q[b].float().unsqueeze(1)  # [Hq,1,d]
+        want = _sdpa_ref(qq, k[b, :, :n].float(), v[b, :, :n].float(), False, hd ** -0.5).reshape(Hq * hd)
+        assert_close_bf16(out[b], want, ulps=4.0, atol=4e-3, what=f"attn_decode read {b} len {n}")
+
+
+# ------------------------------------------------------------------------------------------------ row-wise kernels
+@pytest.mark.parametrize("rows,D", [(5, 64), (1000, 1280), (33, 2048)])
+def test_layernorm(rows, D):
+    x = randbf(rows, D, scale=3.0, seed=18)
+    w = randbf(D, seed=19)
+    b = randbf(D, seed=20)
+    out = torch.empty_like(x)
+    assert lib().hwocr_layernorm(p(x), p(w), p(b), p(out), rows, D, D, D, 1e-6, st()) == 0
+    sync()
+    want = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-6)
+    assert_close_bf16(out, want, ulps=1.0, atol=1e-3, what="layernorm")
+
+
+@pytest.mark.parametrize("rows,D,nslab", [(7, 1536, 0), (96, 1536, 6), (3, 256, 2)])
+def test_add_rmsnorm(rows, D, nslab):
+    h = randbf(rows, D, scale=2.0, seed=21)
+    w = randbf(D, seed=22)
+    bias = randbf(D, seed=23)
+    slabs = torch.randn(max(nslab, 1), rows, D, device=DEV)
+    h_in = h.clone()
+    out = torch.empty_like(h)
+    rc = lib().hwocr_add_rmsnorm(p(slabs) if nslab else None, nslab, rows * D, D, p(bias) if nslab else None, p(h), D,
+                                 p(w), p(out), D, None, rows, D, 1e-6, 0, st())
+    assert rc == 0
+    sync()
+    x = h_in.float()
+    if nslab:
+        y = slabs[:nslab].sum(0) + bias.float()
+        x = rbf(rbf(y) + x)
+        assert_close_bf16(h, x, ulps=1.0, atol=1e-3, what="residual write-back", mag=y.abs() + h_in.float().abs())
+        x = h.float()
+    want = w.float() * rbf(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert_close_bf16(out, want, ulps=1.5, atol=1e-3, what="rmsnorm")
+
+
+def test_add_rmsnorm_gather():
+    rows, D = 50, 1536
+    h = randbf(rows, D, seed=24)
+    w = randbf(D, seed=25)
+    idx = torch.tensor([49, 0, 17], dtype=torch.int32, device=DEV)
+    out = torch.empty(3, D, dtype=torch.bfloat16, device=DEV)
+    assert lib().hwocr_add_rmsnorm(None, 0, 0, 0, None, p(h), D, p(w), p(out), D, p(idx), 3, D, 1e-6, 0, st()) == 0
+    sync()
+    x = h[idx.long()].float()
+    want = w.float() * rbf(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert_close_bf16(out, want, ulps=1.5, atol=1e-3, what="rmsnorm gather")
+
+
+def test_patchify_exact():
+    nimg, H, W, patch, merge, tps = 2, 56, 84, 14, 2, 2
+    kreal, kpad = 3 * tps * patch * patch, 1216
+    g = torch.Generator().manual_seed(26)
+    img = torch.randint(0, 256, (nimg, H, W, 3), generator=g, dtype=torch.uint8)
+    lut = (torch.randn(3, 256, generator=g)).to(torch.bfloat16)
+    gh, gw = H // patch, W // patch
+    P = gh * gw
+    ld = 64
+    out = torch.full((nimg * ld, kpad), 7.0, dtype=torch.bfloat16, device=DEV)
+    img_d, lut_d = img.to(DEV), lut.to(DEV)  # keep alive: the launch only sees raw pointers
+    rc = lib().hwocr_patchify(p(img_d), p(lut_d), p(out), nimg, H, W, patch, merge, tps, kpad, ld, st())
+    assert rc == 0
+    sync()
+    # restatement of HF patchify on the LUT-mapped image (C,H,W)
+    for im in range(nimg):
+        chw = torch.stack([lut[c][img[im, :, :, c].long()] for c in range(3)])  # [3,H,W] bf16
+        x = chw.reshape(3, gh // merge, merge, patch, gw // merge, merge, patch).permute(1, 4, 2, 5, 0, 3, 6)
+        x = x.unsqueeze(5).expand(*x.shape[:5], tps, patch, patch).reshape(P, kreal)
+        got = out[im * ld: im * ld + P].cpu()
+        assert torch.equal(got[:, :kreal], x), "patchify must be an exact gather"
+        assert (got[:, kreal:] == 0).all()
+
+
+def _vit_pos(gh, gw, merge):
+    hp = torch.arange(gh).view(-1, 1).expand(gh, gw)
+    wp = torch.arange(gw).view(1, -1).expand(gh, gw)
+    f = lambda t: t.reshape(gh // merge, merge, gw // merge, merge).permute(0, 2, 1, 3).reshape(-1)
+    return f(hp), f(wp)
+
+
+@pytest.mark.parametrize("hd,heads", [(80, 4), (32, 2)])
+def test_vit_rope_split(hd, heads):
+    gh, gw = 8, 12
+    P = gh * gw
+    tok_ld = 128
+    D = heads * hd
+    qkv = randbf(tok_ld, 3 * D, seed=27)
+    ph, pw = _vit_pos(gh, gw, 2)
+    pos_h = torch.zeros(tok_ld, dtype=torch.int32)
+    pos_w = torch.zeros(tok_ld, dtype=torch.int32)
+    pos_h[:P], pos_w[:P] = ph, pw
+    quarter = hd // 4
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float) / (hd // 2)))
+    tab = torch.arange(64, dtype=torch.float).unsqueeze(-1) * inv  # [64][quarter]
+    cos_t, sin_t = tab.cos().contiguous(), tab.sin().contiguous()
+    Q = torch.zeros(heads, tok_ld, hd, dtype=torch.bfloat16, device=DEV)
+    K = torch.zeros_like(Q)
+    VT = torch.full((heads, hd, tok_ld), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ph_d, pw_d, cos_d, sin_d = pos_h.to(DEV), pos_w.to(DEV), cos_t.to(DEV), sin_t.to(DEV)
+    rc = lib().hwocr_vit_rope_split(p(qkv), p(Q), p(K), p(VT), p(ph_d), p(pw_d), p(cos_d), p(sin_d), P, tok_ld, heads,
+                                    hd, st())
+    assert rc == 0
+    sync()
+    x = qkv[:P].float().cpu().view(P, 3, heads, hd)
+    rot = torch.cat([tab[ph.long()], tab[pw.long()]], -1)  # [P, hd/2]
+    emb = torch.cat([rot, rot], -1)
+    cos, sin = emb.cos().unsqueeze(1), emb.sin().unsqueeze(1)
+    rh = lambda t: torch.cat([-t[..., hd // 2:], t[..., : hd // 2]], -1)
+    for which, got in ((0, Q), (1, K)):
+        want = x[:, which] * cos + rh(x[:, which]) * sin  # [P, heads, hd]
+        assert_close_bf16(got[:, :P].cpu().permute(1, 0, 2), want, ulps=1.0, atol=1e-3, what=f"vit rope {which}")
+    assert torch.equal(VT[:, :, :P].cpu(), qkv[:P].cpu().view(P, 3, heads, hd)[:, 2].permute(1, 2, 0))
+    assert (VT[:, :, P:].cpu() == 0).all()
+    assert quarter * 4 == hd
+
+
+def _mrope_ref(x, pos3, cos_tab, sin_tab, sec0, sec1):
+    # x [rows, heads, 128] fp32 (bf16 values); tables bf16 [maxpos][64]; returns fp32 of the bf16 result
+    i = torch.arange(64)
+    axis = torch.where(i < sec0, 0, torch.where(i < sec1, 1, 2))
+    pidx = pos3[axis, :].t().long()  # [rows, 64]
+    cs = cos_tab.float()[pidx, i].unsqueeze(1)  # [rows,1,64]
+    sn = sin_tab.float()[pidx, i].unsqueeze(1)
+    x1, x2 = x[..., :64], x[..., 64:]
+    oa = rbf(rbf(x1 * cs) + rbf(-x2 * sn))
+    ob = rbf(rbf(x2 * cs) + rbf(x1 * sn))
+    return torch.cat([oa, ob], -1)
+
+
+def _rope_tables(maxpos, theta=1e6):
+    inv = 1.0 / (theta ** (torch.arange(0, 128, 2, dtype=torch.float) / 128))
+    fr = torch.arange(maxpos, dtype=torch.float).unsqueeze(-1) * inv
+    return fr.cos().to(torch.bfloat16), fr.sin().to(torch.bfloat16)
+
+
+def test_mrope_kv_prefill():
+    Hq, Hkv, nseq, Tp, ctx = 4, 2, 2, 128, 256
+    rows = nseq * Tp
+    W = (Hq + 2 * Hkv) * 128
+    qkv = randbf(rows, W, seed=28)
+    g = torch.Generator().manual_seed(29)
+    pos3 = torch.randint(0, 300, (3, rows), generator=g, dtype=torch.int32)
+    cos_t, sin_t = _rope_tables(512)
+    Q = torch.zeros(rows, Hq * 128, dtype=torch.bfloat16, device=DEV)
+    Kc = torch.zeros(nseq, Hkv, ctx, 128, dtype=torch.bfloat16, device=DEV)
+    VT = torch.zeros(nseq, Hkv, 128, ctx, dtype=torch.bfloat16, device=DEV)
+    pos_d, cos_d, sin_d = pos3.to(DEV), cos_t.to(DEV), sin_t.to(DEV)
+    rc = lib().hwocr_mrope_kv_prefill(p(qkv), p(Q), p(Kc), p(VT), p(pos_d), p(cos_d), p(sin_d),
+                                      rows, Tp, Hq, Hkv, 16, 40, Hkv * ctx * 128, ctx * 128, Hkv * 128 * ctx, 128 * ctx,
+                                      ctx, st())
+    assert rc == 0
+    sync()
+    x = qkv.float().cpu()
+    qw = _mrope_ref(x[:, : Hq * 128].view(rows, Hq, 128), pos3, cos_t, sin_t, 16, 40)
+    kw = _mrope_ref(x[:, Hq * 128: (Hq + Hkv) * 128].view(rows, Hkv, 128), pos3, cos_t, sin_t, 16, 40)
+    assert torch.equal(Q.float().cpu().view(rows, Hq, 128), qw), "M-RoPE q must reproduce the bf16 rounding chain"
+    assert torch.equal(Kc[:, :, :Tp].float().cpu(), kw.view(nseq, Tp, Hkv, 128).permute(0, 2, 1, 3))
+    vw = qkv.cpu()[:, (Hq + Hkv) * 128:].view(nseq, Tp, Hkv, 128).permute(0, 2, 3, 1)
+    assert torch.equal(VT[:, :, :, :Tp].cpu(), vw)
+
+
+def test_decode_qkv_finish():
+    Hq, Hkv, B, ctx, nslab = 12, 2, 5, 256, 3
+    W = (Hq + 2 * Hkv) * 128
+    slabs = torch.randn(nslab, B, W, device=DEV)
+    bias = randbf(W, seed=30)
+    lens = torch.tensor([1, 10, 200, 256, 77], dtype=torch.int32)
+    delta = torch.tensor([0, -5, 3, -100, 40], dtype=torch.int32)
+    cos_t, sin_t = _rope_tables(512)
+    Q = torch.zeros(B, Hq * 128, dtype=torch.bfloat16, device=DEV)
+    Kc = torch.zeros(B, Hkv, ctx, 128, dtype=torch.bfloat16, device=DEV)
+    VT = torch.zeros(B, Hkv, 128, ctx, dtype=torch.bfloat16, device=DEV)
+    lens_d, delta_d, cos_d, sin_d = lens.to(DEV), delta.to(DEV), cos_t.to(DEV), sin_t.to(DEV)
+    rc = lib().hwocr_decode_qkv_finish(p(slabs), nslab, B * W, p(bias), p(Q), p(Kc), p(VT), p(lens_d),
+                                       p(delta_d), p(cos_d), p(sin_d), B, Hq, Hkv,
+                                       Hkv * ctx * 128, ctx * 128, Hkv * 128 * ctx, 128 * ctx, ctx, st())
+    assert rc == 0
+    sync()
+    row = rbf((slabs.sum(0) + bias.float()).cpu())
+    pos = (lens - 1 + delta)
+    pos3 = pos.unsqueeze(0).expand(3, B)
+    qw = _mrope_ref(row[:, : Hq * 128].view(B, Hq, 128), pos3, cos_t, sin_t, 16, 40)
+    kw = _mrope_ref(row[:, Hq * 128: (Hq + Hkv) * 128].view(B, Hkv, 128), pos3, cos_t, sin_t, 16, 40)
+    # slab summation order differs from torch.sum by fp32 rounding only -> 1 bf16 ulp
+    assert_close_bf16(Q.view(B, Hq, 128).cpu(), qw, ulps=1.0, atol=1e-3, what="decode q")
+    for b in range(B):
+        slot = int(lens[b]) - 1
+        assert_close_bf16(Kc[b, :, slot].cpu(), kw[b], ulps=1.0, atol=1e-3, what="decode k")
+        assert_close_bf16(VT[b, :, :, slot].cpu(), row[b, (Hq + Hkv) * 128:].view(Hkv, 128), ulps=1.0, atol=1e-3,
+                          what="decode v")
+        assert (Kc[b].float().abs().sum(-1) != 0).sum() == Hkv  # exactly one slot written per kv head
+
+
+def test_embed_splice():
+    V, D, rows = 100, 256, 20
+    table = randbf(V, D, seed=31)
+    img = randbf(6, D, seed=32)
+    ids = torch.arange(rows, dtype=torch.int32) % V
+    img_row = torch.full((rows,), -1, dtype=torch.int32)
+    img_row[3:9] = torch.arange(6, dtype=torch.int32)
+    out = torch.zeros(rows, D, dtype=torch.bfloat16, device=DEV)
+    ids_d, row_d = ids.to(DEV), img_row.to(DEV)
+    assert lib().hwocr_embed_splice(p(ids_d), p(row_d), p(table), p(img), p(out), rows, D, 1.0, st()) == 0
+    sync()
+    want = table[ids.long().to(DEV)].clone()
+    want[3:9] = img
+    assert torch.equal(out, want)
+
+
+def test_argmax_advance_semantics():
+    import ctypes as C
+    V, B, max_new = 1000, 4, 8
+    logits = randbf(B, V, seed=33)
+    logits[0, 10] = 50.0
+    logits[0, 20] = 50.0   # tie -> lowest index (torch.argmax picks the first maximum)
+    logits[1, 999] = 60.0  # EOS wins but n_gen < min_new -> suppressed
+    logits[1, 5] = 55.0
+    logits[2, 999] = 60.0  # EOS, allowed
+    logits[3, 7] = 60.0    # already finished -> pad
+    cur = torch.zeros(B, dtype=torch.int32, device=DEV)
+    lens = torch.tensor([5, 6, 7, 8], dtype=torch.int32, device=DEV)
+    n_gen = torch.tensor([0, 0, 3, 3], dtype=torch.int32, device=DEV)
+    fin = torch.tensor([0, 0, 0, 1], dtype=torch.int32, device=DEV)
+    outt = torch.full((B, max_new), -1, dtype=torch.int32, device=DEV)
+    eos = (C.c_int * 4)(999, 0, 0, 0)
+    rc = lib().hwocr_argmax_advance(p(logits), V, V, B, p(cur), p(lens), p(n_gen), p(fin), p(outt), max_new, 2, eos, 1,
+                                    123, st())
+    assert rc == 0
+    sync()
+    assert cur.tolist() == [10, 5, 999, 123]
+    assert lens.tolist() == [6, 7, 8, 9]
+    assert n_gen.tolist() == [1, 1, 4, 4]
+    assert fin.tolist() == [0, 0, 1, 1]
+    assert outt[0, 0] == 10 and outt[1, 0] == 5 and outt[2, 3] == 999 and outt[3, 3] == 123

@@ -1,0 +1,447 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ (run in the BUILD container, never on the GPU box).
+
+Sources of truth
+  * string / preprocessing / node control-flow KATs: the reference's own Python, imported from /root/reference with an
+    inert `ollama` module in sys.modules (ocr_agent/tools.py:146 imports it at module level; nothing on the paths
+    exercised here calls it).  cv2 is absent in this image, so preprocessing KATs pin the PIL fallbacks.
+  * image-processor and model KATs: Hugging Face transformers (the library run_ocr drives, tools.py:690-765) on tiny
+    seeded random-init Qwen2-VL models — no checkpoint is available offline.
+
+Only data is written: inputs, expected outputs, weights of the random tiny model.  No reference source text.
+Usage: python tools/make_goldens.py [--only text,preprocess,nodes,image,model]
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import io
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def _import_reference_tools():
+    sys.modules.setdefault("ollama", types.ModuleType("ollama"))  # inert: never called
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import ocr_agent.tools as tools  # noqa
+
+    return tools
+
+
+# ------------------------------------------------------------------------------------------------ text
+WORDS = ("the quick brown fox jumps over a lazy dog while handwritten notes drift across ruled paper and ink "
+         "fades near margins where someone once wrote dates names sums and little reminders to buy milk").split()
+
+
+def _rand_text(rng: random.Random, n: int) -> str:
+    out = []
+    for _ in range(n):
+        w = rng.choice(WORDS)
+        r = rng.random()
+        if r < 0.08:
+            w = w.capitalize()
+        elif r < 0.12:
+            w = w.upper()
+        elif r < 0.16:
+            w += rng.choice(",.;:!?")
+        out.append(w)
+    return " ".join(out)
+
+
+def _mutate(rng: random.Random, s: str, rate: float) -> str:
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < rate / 3:
+            continue
+        if r < 2 * rate / 3:
+            out.append(rng.choice("abcdefghijklmnopqrstuvwxyz "))
+            continue
+        out.append(ch)
+        if r < rate:
+            out.append(rng.choice("aeiou \n"))
+    return "".join(out)
+
+
+def make_text(tools) -> None:
+    rng = random.Random(1234)
+    pairs = [("", ""), ("", "abc"), ("abc", ""), ("kitten", "sitting"), ("a", "a"), ("A", "a"),
+             ("‘quoted’ “text” – dash — em", "'quoted' \"text\" - dash - em"),
+             ("  many   spaces\n\nand\tlines ", "many spaces and lines"),
+             ("The Cat sat", "the cat SAT"), ("one two three", "three two one"),
+             ("été naïve 中文 \U0001f600", "ete naive 中 \U0001f600"),
+             ("x" * 70, "x" * 63 + "y"), ("ab" * 100, "ba" * 100)]
+    for _ in range(200):
+        n = rng.choice([1, 2, 5, 12, 40, 90])
+        a = _rand_text(rng, n)
+        b = _mutate(rng, a, rng.choice([0.0, 0.02, 0.1, 0.4]))
+        pairs.append((a, b))
+    cases = []
+    for a, b in pairs:
+        na, nb = tools.normalize_text(a), tools.normalize_text(b)
+        cases.append({
+            "a": a, "b": b,
+            "normalize_a": na, "normalize_a_lower": tools.normalize_text(a, True),
+            "levenshtein": tools.levenshtein(na, nb),
+            "levenshtein_words": tools._levenshtein_words(na.split(), nb.split()),
+            "cer": tools.cer(a, b), "wer": tools.wer(a, b), "cer_lower": tools.cer(a, b, True),
+            "tier1": tools.tier1_metrics(a, b),
+            "compare": tools.compare_versions(a, b),
+        })
+    merges = [[], ["solo text"], ["a b c", "a b c"], ["the Cat sat", "the cat sat"], ["The cat", "the cat", "THE cat"],
+              ["a b c d", "a x c d", "a b c"], ["same len one", "same len two"], ["x", "y z", "y z w"]]
+    for _ in range(80):
+        base = _rand_text(rng, rng.choice([3, 10, 30, 80]))
+        k = rng.choice([2, 3, 3, 4])
+        merges.append([_mutate(rng, base, rng.choice([0.0, 0.03, 0.15])) for _ in range(k)])
+    mcases = [{"versions": v, "merged": tools.merge_versions(v)} for v in merges]
+    aligns = []
+    for _ in range(40):
+        a = _rand_text(rng, rng.choice([1, 4, 15, 40])).split()
+        b = _mutate(rng, " ".join(a), 0.2).split()
+        aligns.append({"backbone": a, "words": b, "aligned": tools._align_to_backbone(a, b)})
+    long_a = _rand_text(rng, 260)
+    long_b = _mutate(rng, long_a, 0.05)
+    longc = {"a": long_a, "b": long_b, "compare": tools.compare_versions(long_a, long_b),
+             "merged3": tools.merge_versions([long_a, long_b, _mutate(rng, long_a, 0.05)])}
+    longc["third"] = None  # merged3's third input is not reproducible from the rng state; store it explicitly
+    third = _mutate(random.Random(99), long_a, 0.05)
+    longc["third"] = third
+    longc["merged3"] = tools.merge_versions([long_a, long_b, third])
+    gt_cases = []
+    for text in ["# Title\n\n## Ground Truth\n\nhello world\n", "no header here\n", "## Ground Truth\n", ""]:
+        import tempfile
+        with tempfile.NamedTemporaryFile("w", suffix=".md", delete=False, encoding="utf-8") as f:
+            f.write(text)
+        gt_cases.append({"file_text": text, "parsed": tools.parse_ground_truth(f.name)})
+        os.unlink(f.name)
+    js = [{"raw": r, "parsed": tools.parse_json_response(r)} for r in
+          ['{"a": 1}', '```json\n{"a": [1, 2]}\n```', 'noise {"k": {"n": 2}} tail', "[1, 2, 3]", "not json", "{broken"]]
+    with open(os.path.join(GOLD, "text_kats.json"), "w", encoding="utf-8") as f:
+        json.dump({"source": "ocr_agent.tools imported from /root/reference (inert ollama stub)", "pairs": cases,
+                   "merges": mcases, "aligns": aligns, "long": longc, "ground_truth": gt_cases, "json": js}, f,
+                  ensure_ascii=True, indent=0)
+    print("text_kats.json:", len(cases), "pairs,", len(mcases), "merges")
+
+
+# ------------------------------------------------------------------------------------------------ synthetic pages
+def make_page(seed: int, h: int, w: int, ruled: bool = True) -> np.ndarray:
+    """Synthetic handwritten page: bright noisy paper, dark stroke polylines, optional ruled lines."""
+    from PIL import Image, ImageDraw
+
+    rng = np.random.default_rng(seed)
+    paper = rng.integers(200, 256, size=(h, w, 1), dtype=np.uint8).repeat(3, axis=2)
+    img = Image.fromarray(paper, "RGB")
+    d = ImageDraw.Draw(img)
+    nlines = max(2, h // 42)
+    for i in range(nlines):
+        y0 = int((i + 0.6) * h / nlines)
+        if ruled:
+            d.line([(0, y0 + 6), (w, y0 + 6)], fill=(150, 170, 210), width=1)
+        x = int(rng.integers(4, 12))
+        while x < w - 8:
+            n = int(rng.integers(3, 7))
+            pts = [(x + int(rng.integers(0, 10)) + 4 * k, y0 + int(rng.integers(-9, 7))) for k in range(n)]
+            ink = int(rng.integers(0, 81))
+            d.line(pts, fill=(ink, ink, ink), width=int(rng.integers(2, 5)))
+            x += 4 * n + int(rng.integers(6, 18))
+    return np.asarray(img)
+
+
+def make_preprocess(tools) -> None:
+    import tempfile
+    from PIL import Image
+    from ocr_agent import config
+
+    cases = []
+    tmpd = tempfile.mkdtemp()
+    for seed, (h, w), mode in [(0, (64, 64), "RGB"), (1, (128, 96), "RGB"), (2, (256, 256), "RGB"), (3, (100, 140), "L")]:
+        arr = make_page(seed, h, w)
+        img = Image.fromarray(arr, "RGB")
+        if mode == "L":
+            img = img.convert("L")
+        src = os.path.join(tmpd, f"page{seed}.png")
+        img.save(src)
+        strategies = [list(s) for s in config.PREPROCESSING_STRATEGIES] + ["original", ["original"], "sharpen",
+                                                                         ["binarize", "sharpen"], ["nope", "sharpen"]]
+        for strat in strategies:
+            buf = io.StringIO()
+            old = sys.stdout
+            sys.stdout = buf
+            try:
+                out = tools.preprocess_image(src, strat)
+            finally:
+                sys.stdout = old
+            same = out == src
+            res = Image.open(out)
+            px = np.asarray(res)
+            cases.append({"seed": seed, "h": h, "w": w, "mode": mode, "strategy": strat, "returns_input_path": same,
+                          "out_mode": res.mode, "out_size": list(res.size),
+                          "pixels_sha256": hashlib.sha256(px.tobytes()).hexdigest(),
+                          "prefix": os.path.basename(out).split("_")[0] if not same else None,
+                          "basename_starts": None if same else os.path.basename(out)[: len("ocr_" + "+".join(
+                              s for s in (strat if isinstance(strat, list) else [strat]) if s != "original") + "_")],
+                          "suffix": os.path.splitext(out)[1], "stdout": buf.getvalue()})
+            if not same:
+                os.unlink(out)
+    with open(os.path.join(GOLD, "preprocess_kats.json"), "w") as f:
+        json.dump({"cv2_available": False, "source": "ocr_agent.tools.preprocess_image (PIL fallbacks)",
+                   "strategies_config": [list(s) for s in config.PREPROCESSING_STRATEGIES], "cases": cases}, f, indent=0)
+    print("preprocess_kats.json:", len(cases), "cases")
+
+
+# ------------------------------------------------------------------------------------------------ nodes
+def make_nodes() -> None:
+    """Control-flow KAT: the reference's node_initial_ocr / node_reocr with scripted run_ocr / preprocess / arbitrator."""
+    tools = _import_reference_tools()
+    sys.modules.setdefault("pydantic", __import__("pydantic"))
+    import ocr_agent.nodes as nodes
+    from ocr_agent import config
+    import time
+
+    scripts = {
+        "agree": ["the quick brown fox jumps", "the quick brown fox jumps", "never read"],
+        "disagree": ["the quick brown fox jumps over", "a completely different reading here", "the quick brown fax jumps over"],
+        "case_tie": ["The cat sat down", "the cat sat down", "THE cat sat down"],
+    }
+    out = {}
+    for name, texts in scripts.items():
+        calls = {"n": 0, "pre": []}
+
+        def fake_ocr(path, params=None, _c=calls, _t=texts):
+            t = _t[min(_c["n"], len(_t) - 1)]
+            _c["n"] += 1
+            return t
+
+        def fake_pre(path, strategy, _c=calls):
+            _c["pre"].append(strategy if isinstance(strategy, str) else list(strategy))
+            return path + "#" + ("+".join(strategy) if isinstance(strategy, list) else strategy)
+
+        nodes.run_ocr, nodes.preprocess_image, nodes.unload_ocr_model = fake_ocr, fake_pre, (lambda: None)
+        state = {"image_path": "/pages/p1.png", "candidates": [], "critiques": [], "edits": [], "current_best": "",
+                 "current_score": 0.0, "iteration": 0, "max_iterations": 3, "status": "running", "reason": "",
+                 "strategies_used": [], "plateau_count": 0, "prev_score": 0.0, "prev_critique": None,
+                 "config": {"accept_threshold": 85, "plateau_patience": 2,
+                            "strategies": [list(s) for s in config.PREPROCESSING_STRATEGIES],
+                            "agreement_threshold": config.AGREEMENT_THRESHOLD},
+                 "trace_events": [], "start_time": time.monotonic()}
+        buf = io.StringIO()
+        old = sys.stdout
+        sys.stdout = buf
+        try:
+            upd = nodes.node_initial_ocr(state)
+        finally:
+            sys.stdout = old
+
+        def strip(ev):
+            ev = dict(ev)
+            ev.pop("timestamp"), ev.pop("elapsed_seconds")
+            return ev
+
+        rec = {"texts": texts, "update": {k: ([strip(e) for e in v] if k == "trace_events" else v) for k, v in upd.items()},
+               "preprocess_calls": calls["pre"], "ocr_calls": calls["n"],
+               "stdout_lines": [ln.split("] ", 1)[-1] if ln.startswith("[") else ln for ln in buf.getvalue().splitlines()]}
+        # re-OCR rounds until the strategies are exhausted (arbitrator scripted: keeps the longer text)
+        state.update(upd)
+
+        class Arb:
+            def __init__(self, text):
+                self.final_text, self.confidence, self.decisions, self.uncertain_segments = text, 77, [], []
+
+            def model_dump(self):
+                return {"final_text": self.final_text, "confidence": self.confidence, "decisions": [], "uncertain_segments": []}
+
+        nodes.run_arbitrator = lambda versions: Arb(max((v["text"] for v in versions), key=len))
+        rounds = []
+        for _ in range(6):
+            sys.stdout = io.StringIO()
+            try:
+                u = nodes.node_reocr(state)
+            finally:
+                sys.stdout = old
+            rounds.append({k: ([strip(e) for e in v] if k == "trace_events" else v) for k, v in u.items()})
+            state.update(u)
+            if u.get("reason") == "exhausted":
+                break
+        rec["reocr_rounds"] = rounds
+        out[name] = rec
+    with open(os.path.join(GOLD, "nodes_kats.json"), "w") as f:
+        json.dump({"source": "ocr_agent.nodes with scripted run_ocr / preprocess_image / run_arbitrator", "cases": out}, f,
+                  indent=0, default=str)
+    print("nodes_kats.json:", list(out))
+
+
+# ------------------------------------------------------------------------------------------------ image processor
+def make_image() -> None:
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil, smart_resize
+    from PIL import Image
+
+    table = []
+    for (h, w) in [(512, 512), (1024, 1024), (896, 896), (1000, 700), (333, 517), (2000, 3000), (100, 100), (28, 5000),
+                   (57, 83), (4032, 3024), (255, 257), (1, 1), (27, 27), (3000, 20)]:
+        for (mn, mx) in [(256 * 256, 1024 * 1024), (56 * 56, 14 * 14 * 4 * 1280)]:
+            try:
+                r = list(smart_resize(h, w, 28, mn, mx))
+            except ValueError as e:
+                r = "ValueError"
+            table.append({"h": h, "w": w, "min_pixels": mn, "max_pixels": mx, "out": r})
+    from safetensors.torch import save_file
+
+    tensors = {}
+    meta = []
+    for idx, (seed, (h, w), (mn, mx)) in enumerate([(5, (60, 90), (28 * 28, 1024 * 1024)), (6, (150, 200), (28 * 28, 1024 * 1024)),
+                                                     (7, (120, 100), (256 * 256, 1024 * 1024))]):
+        arr = make_page(seed, h, w)
+        proc = Qwen2VLImageProcessorPil(min_pixels=mn, max_pixels=mx)
+        out = proc(images=[Image.fromarray(arr, "RGB")], return_tensors="pt")
+        tensors[f"img{idx}.page"] = torch.from_numpy(arr.copy())
+        tensors[f"img{idx}.pixel_values"] = out["pixel_values"].contiguous()
+        meta.append({"seed": seed, "h": h, "w": w, "min_pixels": mn, "max_pixels": mx,
+                     "grid_thw": out["image_grid_thw"][0].tolist()})
+    save_file(tensors, os.path.join(GOLD, "image_kats.safetensors"))
+    with open(os.path.join(GOLD, "image_kats.json"), "w") as f:
+        json.dump({"source": "transformers Qwen2VLImageProcessorPil / smart_resize", "smart_resize": table, "images": meta,
+                   "image_mean": [0.48145466, 0.4578275, 0.40821073], "image_std": [0.26862954, 0.26130258, 0.27577711]}, f,
+                  indent=0)
+    print("image_kats:", len(table), "smart_resize rows,", len(meta), "images")
+
+
+# ------------------------------------------------------------------------------------------------ model
+TINY = dict(
+    vision=dict(depth=2, embed_dim=64, hidden_size=256, hidden_act="quick_gelu", mlp_ratio=2, num_heads=2, in_channels=3,
+                patch_size=14, spatial_merge_size=2, temporal_patch_size=2),
+    text=dict(vocab_size=512, hidden_size=256, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+              num_key_value_heads=1, max_position_embeddings=4096, rms_norm_eps=1e-6, tie_word_embeddings=True,
+              rope_parameters={"rope_type": "default", "rope_theta": 1000000.0, "mrope_section": [16, 24, 24]}),
+    image_token_id=500, video_token_id=501, vision_start_token_id=502, vision_end_token_id=503, eos=510, pad=511)
+
+
+def build_tiny_hf(dtype: torch.dtype):
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+
+    cfg = Qwen2VLConfig(vision_config=dict(TINY["vision"]), text_config=dict(TINY["text"]),
+                        image_token_id=TINY["image_token_id"], video_token_id=TINY["video_token_id"],
+                        vision_start_token_id=TINY["vision_start_token_id"], vision_end_token_id=TINY["vision_end_token_id"],
+                        tie_word_embeddings=True)
+    torch.manual_seed(0)
+    model = Qwen2VLForConditionalGeneration(cfg).eval()
+    g = torch.Generator().manual_seed(20260504)
+    with torch.no_grad():
+        for name, prm in sorted(model.named_parameters()):
+            if name.endswith("norm.weight") or "norm1.weight" in name or "norm2.weight" in name or "ln_q.weight" in name \
+                    or "layernorm.weight" in name:
+                v = 1.0 + 0.1 * torch.randn(prm.shape, generator=g)
+            elif name.endswith(".bias"):
+                v = 0.05 * torch.randn(prm.shape, generator=g)
+            elif "embed_tokens" in name:
+                v = 0.08 * torch.randn(prm.shape, generator=g)
+            else:
+                v = torch.randn(prm.shape, generator=g) * (1.5 / (prm.shape[-1] if prm.dim() < 3 else prm[0].numel()) ** 0.5)
+            prm.copy_(v.to(torch.bfloat16).to(prm.dtype))  # bf16-representable, so one weight file serves both dtypes
+    model.tie_weights()
+    return model.to(dtype), cfg
+
+
+def make_model() -> None:
+    from safetensors.torch import save_file
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+    from PIL import Image
+
+    proc = Qwen2VLImageProcessorPil(min_pixels=28 * 28, max_pixels=1024 * 1024)
+    cases = [("a", 11, (60, 90)), ("b", 12, (150, 200))]
+    rng = np.random.default_rng(77)
+    weights_saved = False
+    meta = {"config": {k: v for k, v in TINY.items()}, "cases": {}, "source": "transformers Qwen2VLForConditionalGeneration, "
+            "random init (seeded), greedy, min_new_tokens == max_new_tokens"}
+    N_NEW = 24
+    for dtype, tag in [(torch.float32, "fp32"), (torch.bfloat16, "bf16")]:
+        model, cfg = build_tiny_hf(dtype)
+        model.generation_config.eos_token_id = TINY["eos"]
+        model.generation_config.pad_token_id = TINY["pad"]
+        if not weights_saved:
+            sd = {k: v.to(torch.bfloat16).contiguous() for k, v in model.state_dict().items() if k != "lm_head.weight"}
+            save_file(sd, os.path.join(GOLD, "qwen2vl_tiny_weights.safetensors"))
+            weights_saved = True
+        tensors = {}
+        for cname, seed, (h, w) in cases:
+            page = make_page(seed, h, w)
+            out = proc(images=[Image.fromarray(page, "RGB")], return_tensors="pt")
+            pv, grid = out["pixel_values"], out["image_grid_thw"]
+            n_img = int(grid[0].prod()) // 4
+            crng = np.random.default_rng(1000 + seed)
+            pre = crng.integers(0, 500, size=5).tolist()
+            suf = crng.integers(0, 500, size=6).tolist()
+            ids = pre + [TINY["vision_start_token_id"]] + [TINY["image_token_id"]] * n_img + [TINY["vision_end_token_id"]] + suf
+            input_ids = torch.tensor([ids])
+            mm = (input_ids == TINY["image_token_id"]).int()
+            acts = {}
+
+            def hook(name):
+                def fn(mod, inp, outp):
+                    acts[name] = (outp[0] if isinstance(outp, tuple) else outp).detach().clone()
+                return fn
+
+            vis = model.model.visual
+            hs = [vis.patch_embed.register_forward_hook(hook("patch_embed")), vis.blocks[0].register_forward_hook(hook("vit_block0")),
+                  vis.blocks[-1].register_forward_hook(hook("vit_last")), vis.merger.register_forward_hook(hook("merger")),
+                  model.model.language_model.layers[0].register_forward_hook(hook("dec_layer0"))]
+            with torch.no_grad():
+                fw = model(input_ids=input_ids, pixel_values=pv, image_grid_thw=grid, mm_token_type_ids=mm,
+                           attention_mask=torch.ones_like(input_ids))
+                pos, delta = model.model.get_rope_index(input_ids, mm, image_grid_thw=grid)
+            for hdl in hs:
+                hdl.remove()
+            with torch.no_grad():
+                gen = model.generate(input_ids=input_ids, pixel_values=pv, image_grid_thw=grid, mm_token_type_ids=mm,
+                                     attention_mask=torch.ones_like(input_ids), do_sample=False, max_new_tokens=N_NEW,
+                                     min_new_tokens=N_NEW, output_logits=True, return_dict_in_generate=True)
+            new = gen.sequences[0, input_ids.shape[1]:]
+            tensors[f"{cname}.page"] = torch.from_numpy(page.copy())
+            tensors[f"{cname}.pixel_values"] = pv.contiguous()
+            tensors[f"{cname}.input_ids"] = input_ids[0].to(torch.int32)
+            tensors[f"{cname}.position_ids"] = pos[:, 0].to(torch.int32).contiguous()
+            tensors[f"{cname}.prefill_logits"] = fw.logits[0].contiguous()
+            tensors[f"{cname}.greedy_tokens"] = new.to(torch.int32)
+            tensors[f"{cname}.step_logits"] = torch.stack([l[0] for l in gen.logits]).contiguous()
+            for k, v in acts.items():
+                tensors[f"{cname}.{k}"] = (v[0] if v.dim() == 3 else v).contiguous()
+            meta["cases"][cname] = {"page_seed": seed, "page_hw": [h, w], "grid_thw": grid[0].tolist(), "n_new": N_NEW,
+                                    "rope_delta": int(delta[0]), "T": len(ids)}
+        save_file(tensors, os.path.join(GOLD, f"qwen2vl_tiny_{tag}.safetensors"))
+        print(f"qwen2vl_tiny_{tag}.safetensors:", {k: tuple(v.shape) for k, v in tensors.items() if k.startswith("a.")})
+    with open(os.path.join(GOLD, "qwen2vl_tiny.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="text,preprocess,nodes,image,model")
+    only = set(ap.parse_args().only.split(","))
+    os.makedirs(GOLD, exist_ok=True)
+    if only & {"text", "preprocess"}:
+        tools = _import_reference_tools()
+        if "text" in only:
+            make_text(tools)
+        if "preprocess" in only:
+            make_preprocess(tools)
+    if "nodes" in only:
+        make_nodes()
+    if "image" in only:
+        make_image()
+    if "model" in only:
+        make_model()
+
+
+if __name__ == "__main__":
+    main()
