@@ -89,6 +89,8 @@ _HIP_SIGS = {
                                    C.POINTER(P)], I),
     "hwocr_decode_graph_launch": ([P, I, P], I),
     "hwocr_decode_graph_destroy": ([P], I),
+    "hwocr_profile_enable": ([I], I),
+    "hwocr_profile_read": ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)], I),
 }
 
 _TEXT_SIGS = {

@@ -397,6 +397,7 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
                                   long q_seg, long q_head, long q_row, long k_seg, long k_head, long k_row,
                                   long v_seg, long v_head, long v_row, long o_seg, long o_row, float scale,
                                   hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseg <= 0 || heads <= 0 || group <= 0 || max_len <= 0) return HWOCR_EINVAL;
   if ((q_row % 8) || (k_row % 8) || (v_row % 8) || (o_row % 4) || (q_head % 8) || (k_head % 8) || (v_head % 8) ||
       (q_seg % 8) || (k_seg % 8) || (v_seg % 8))
@@ -419,6 +420,7 @@ extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, c
                                  float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit,
                                  long k_seq, long k_head, long v_seq, long v_head, long v_row, float scale,
                                  hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseq <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16 || nsplit < 1) return HWOCR_EINVAL;
   if (nsplit > 1 && (!part_o || !part_ml)) return HWOCR_EINVAL;
   if ((v_row % 64) || (k_seq % 8) || (k_head % 8) || (v_seq % 8) || (v_head % 8)) return HWOCR_EINVAL;

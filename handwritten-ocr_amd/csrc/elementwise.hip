@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256) void argmax_advance_kernel(SelectArgs a) {
 
 extern "C" int hwocr_patchify(const void* img, const void* lut, void* out, int nimg, int H, int W, int patch,
                               int merge, int tps, int kpad, int rows_per_img_ld, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nimg <= 0 || H % (patch * merge) || W % (patch * merge) || kpad % 8 || kpad < 3 * tps * patch * patch ||
       rows_per_img_ld < (H / patch) * (W / patch))
     return HWOCR_EINVAL;
@@ -440,6 +441,7 @@ extern "C" int hwocr_patchify(const void* img, const void* lut, void* out, int n
 
 extern "C" int hwocr_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int D, int ldx,
                                int ldo, float eps, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldx % 8 || ldo % 8) return HWOCR_EINVAL;
   LayerNormArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)out, rows, D, ldx, ldo, eps};
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
@@ -449,6 +451,7 @@ extern "C" int hwocr_layernorm(const void* x, const void* w, const void* b, void
 extern "C" int hwocr_add_rmsnorm(const float* slabs, int nslab, long slab_stride, int ld_slab, const void* bias,
                                  void* h, int ldh, const void* w, void* out, int ldo, const int* row_index,
                                  int rows, int D, float eps, int gemma, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldh % 8 || ldo % 8 || (nslab > 0 && (!slabs || ld_slab % 4)))
     return HWOCR_EINVAL;
   if (nslab > 0 && row_index) return HWOCR_EINVAL;
@@ -461,6 +464,7 @@ extern "C" int hwocr_add_rmsnorm(const float* slabs, int nslab, long slab_stride
 extern "C" int hwocr_vit_rope_split(const void* qkv, void* Q, void* K, void* VT, const int* pos_h, const int* pos_w,
                                     const float* cos_tab, const float* sin_tab, int tokens, int tok_ld, int heads,
                                     int hd, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (tokens <= 0 || tok_ld % 64 || tok_ld < tokens || hd % 16 || hd > 128) return HWOCR_EINVAL;
   VitRopeArgs a{(const bf16*)qkv, (bf16*)Q, (bf16*)K, (bf16*)VT, pos_h, pos_w, cos_tab, sin_tab,
                 tokens, tok_ld, heads, hd, (long)tok_ld * hd, (long)hd * tok_ld};
@@ -472,6 +476,7 @@ extern "C" int hwocr_mrope_kv_prefill(const void* qkv, void* Q, void* K, void* V
                                       const void* cos_tab, const void* sin_tab, int rows, int rows_per_seq, int Hq,
                                       int Hkv, int sec0, int sec1, long k_seq, long k_head, long v_seq, long v_head,
                                       long v_row, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (rows <= 0 || Hq <= 0 || Hkv <= 0 || rows_per_seq <= 0 || rows_per_seq > v_row) return HWOCR_EINVAL;
   MropeArgs a{(const bf16*)qkv, (bf16*)Q, (bf16*)K, (bf16*)VT, pos, (const bf16*)cos_tab,
               (const bf16*)sin_tab, rows, rows_per_seq, Hq, Hkv, sec0, sec1, k_seq, k_head, v_seq, v_head, v_row};
@@ -484,6 +489,7 @@ extern "C" int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_
                                        const void* cos_tab, const void* sin_tab, int nseq, int Hq, int Hkv,
                                        long k_seq, long k_head, long v_seq, long v_head, long v_row,
                                        hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseq <= 0 || nslab < 1 || !slabs) return HWOCR_EINVAL;
   DecQkvArgs a{slabs, nslab, slab_stride, (const bf16*)bias, (bf16*)Q, (bf16*)K, (bf16*)VT, lens, rope_delta,
                (const bf16*)cos_tab, (const bf16*)sin_tab, Hq, Hkv, k_seq, k_head, v_seq, v_head, v_row};
@@ -493,6 +499,7 @@ extern "C" int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_
 
 extern "C" int hwocr_embed_splice(const int* ids, const int* img_row, const void* table, const void* img, void* out,
                                   int rows, int D, float scale, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (rows <= 0 || D % 8) return HWOCR_EINVAL;
   EmbedArgs a{ids, img_row, (const bf16*)table, (const bf16*)img, (bf16*)out, rows, D, scale};
   const long total = (long)rows * (D / 8);
@@ -503,6 +510,7 @@ extern "C" int hwocr_embed_splice(const int* ids, const int* img_row, const void
 extern "C" int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_ids, int* lens, int* n_gen,
                                     int* finished, int* out_tokens, int max_new, int min_new, const int* eos,
                                     int n_eos, int pad_id, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseq <= 0 || V % 8 || ldl % 8 || n_eos < 0 || n_eos > 4) return HWOCR_EINVAL;
   SelectArgs a{(const bf16*)logits, ldl, V, cur_ids, lens, n_gen, finished, out_tokens, max_new, min_new,
                {0, 0, 0, 0}, n_eos, pad_id};

@@ -18,6 +18,7 @@
 // (HF modeling_qwen2_vl.py:293-301 VisionMlp, :453-466 Qwen2MLP, :442-448 residual adds).
 #include "common.cuh"
 #include "hwocr.h"
+#include <vector>
 
 namespace {
 
@@ -321,9 +322,49 @@ int launch_skinny(const SkinnyArgs& a, int epi, int splitk, hipStream_t st) {
 
 }  // namespace
 
+// ---- optional in-stream timing of gemm_wide launches (bench.py roofline leg): HIP events recorded on the launch
+// stream around every launch while enabled; a few microseconds of overhead per launch, no host sync.
+namespace {
+constexpr int PROF_CAP = 1 << 15;
+struct WideProfile {
+  bool on = false;
+  int n = 0;
+  std::vector<hipEvent_t> ev;      // 2 per launch
+  std::vector<double> flops;
+} g_prof;
+}  // namespace
+
+extern "C" int hwocr_profile_enable(int on) {
+  if (on && g_prof.ev.empty()) {
+    g_prof.ev.resize(2 * PROF_CAP);
+    g_prof.flops.resize(PROF_CAP);
+    for (auto& e : g_prof.ev)
+      if (hipEventCreate(&e) != hipSuccess) return HWOCR_ELAUNCH;
+  }
+  g_prof.on = on != 0;
+  if (on) g_prof.n = 0;
+  return HWOCR_OK;
+}
+
+// sums over the launches recorded since the last enable; the caller must have synchronised the stream
+extern "C" int hwocr_profile_read(double* total_ms, double* total_flops, long* launches) {
+  double ms = 0.0, fl = 0.0;
+  for (int i = 0; i < g_prof.n; ++i) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return HWOCR_ELAUNCH;
+    ms += t;
+    fl += g_prof.flops[i];
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = g_prof.n;
+  return HWOCR_OK;
+}
+
 extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, const void* res, void* out,
                                int M, int N, int K, int ldx, int ldw, int ldo, int ldres, int epi,
                                hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 8) != 0 || (ldx % 8) || (ldw % 8) || (ldo % 4))
     return HWOCR_EINVAL;
   if (epi == EPI_SWIGLU && ((N % 32) != 0 || bias)) return HWOCR_EINVAL;
@@ -340,6 +381,8 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
     attr_done = true;
   }
+  const bool prof = g_prof.on && g_prof.n < PROF_CAP;
+  if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
   switch (epi) {
     case EPI_LINEAR: hipLaunchKernelGGL(gemm_wide_kernel<EPI_LINEAR>, grid, block, WIDE_LDS, stream, a); break;
     case EPI_RESIDUAL: hipLaunchKernelGGL(gemm_wide_kernel<EPI_RESIDUAL>, grid, block, WIDE_LDS, stream, a); break;
@@ -348,11 +391,17 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
     case EPI_SWIGLU: hipLaunchKernelGGL(gemm_wide_kernel<EPI_SWIGLU>, grid, block, WIDE_LDS, stream, a); break;
     default: return HWOCR_EINVAL;
   }
+  if (prof) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], stream);
+    g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
+    ++g_prof.n;
+  }
   return hwocr_launch_status();
 }
 
 extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out, int Bsz, int N,
                                  int K, int ldx, int ldw, int ldo, int epi, int splitk, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (Bsz <= 0 || Bsz > 128 || N <= 0 || K <= 0 || (K % 32) || (N % 16) || (epi == EPI_SWIGLU && (N % 32)) || (ldx % 8) || (ldw % 8) || (ldo % 4) ||
       splitk < 1)
     return HWOCR_EINVAL;

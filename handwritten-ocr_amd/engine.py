@@ -1,0 +1,516 @@
+"""Read engine: the MI355X-native replacement for `model.generate` on the reference's OCR path
+(ocr_agent/tools.py:764-765) for the Qwen2-VL family.
+
+Python here is plumbing only — shapes, index tables, buffer ownership (torch-ROCm tensors) and three calls into
+libhwocr_hip.so per batch of reads:
+
+    hwocr_vit_forward   page pixels -> image embeddings           (vision tower, batched over pages)
+    hwocr_prefill       prompt with spliced image embeddings -> KV cache + first token
+    hwocr_decode_graph  one captured HIP graph replayed once per generated token, all reads in lockstep
+
+Weights stay resident in HBM for the life of the engine (the reference reloads the checkpoint after every
+unload_ocr_model(), nodes.py:127,265); a "read" is one (page, preprocessing strategy) pair and the batch dimension
+of every decode step is the number of reads in flight, so the decoder weights stream from HBM once per step for
+all of them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib, imageproc
+
+HD = 128  # decoder head_dim the kernels are built for
+
+
+@dataclass
+class ModelConfig:
+    name: str = "qwen2-vl-2b"
+    # vision tower
+    depth: int = 32
+    embed_dim: int = 1280
+    num_heads: int = 16
+    mlp_ratio: float = 4.0
+    patch_size: int = 14
+    merge: int = 2
+    tps: int = 2
+    # decoder
+    hidden: int = 1536
+    layers: int = 28
+    q_heads: int = 12
+    kv_heads: int = 2
+    inter: int = 8960
+    vocab: int = 151936
+    rope_theta: float = 1_000_000.0
+    mrope_section: tuple = (16, 24, 24)
+    eps: float = 1e-6
+    tie: bool = True
+    # special tokens
+    image_token_id: int = 151655
+    vision_start_id: int = 151652
+    vision_end_id: int = 151653
+    im_start_id: int = 151644
+    im_end_id: int = 151645
+    eos_ids: tuple = (151645, 151643)
+    pad_id: int = 151643
+    # processor bounds (ocr_agent/config.py:17-18)
+    min_pixels: int = 256 * 256
+    max_pixels: int = 1024 * 1024
+
+    @property
+    def vit_hd(self) -> int:
+        return self.embed_dim // self.num_heads
+
+    @property
+    def mlp_dim(self) -> int:
+        return int(self.embed_dim * self.mlp_ratio)
+
+    @property
+    def patch_k(self) -> int:
+        return 3 * self.tps * self.patch_size ** 2
+
+    @property
+    def kpad(self) -> int:
+        return (self.patch_k + 63) // 64 * 64
+
+    def validate(self) -> None:
+        if self.hidden // self.q_heads != HD:
+            raise ValueError(f"decoder head_dim must be {HD}")
+        if self.vit_hd not in (32, 64, 80, 128):
+            raise ValueError("vision head_dim must be one of 32/64/80/128")
+        if self.embed_dim % 64 or self.hidden % 64 or self.inter % 64 or self.vocab % 32 or self.mlp_dim % 64:
+            raise ValueError("widths must be multiples of 64 (vocab: 32)")
+        if sum(self.mrope_section) * 2 != HD:
+            raise ValueError("mrope_section must sum to head_dim/2")
+
+
+def preset(name: str) -> ModelConfig:
+    """Shapes of BASELINE.json's configs (public model-card values)."""
+    if name in ("qwen2-vl-2b", "Qwen/Qwen2-VL-2B-Instruct"):
+        return ModelConfig()
+    if name == "tiny":  # tests/golden/qwen2vl_tiny.json
+        return ModelConfig(name="tiny", depth=2, embed_dim=64, num_heads=2, mlp_ratio=2, hidden=256, layers=2, q_heads=2,
+                           kv_heads=1, inter=256, vocab=512, image_token_id=500, vision_start_id=502, vision_end_id=503,
+                           im_start_id=504, im_end_id=505, eos_ids=(510,), pad_id=511, min_pixels=28 * 28)
+    if name == "small":  # BASELINE config 1: ViT-S-like + ~125M decoder (head_dim fixed to 128 by the kernels)
+        return ModelConfig(name="small", depth=12, embed_dim=384, num_heads=6, mlp_ratio=4, hidden=768, layers=12,
+                           q_heads=6, kv_heads=2, inter=3072, vocab=32768, image_token_id=32000, vision_start_id=32001,
+                           vision_end_id=32002, im_start_id=32003, im_end_id=32004, eos_ids=(32004,), pad_id=32005)
+    raise ValueError(f"unknown model preset {name!r}")
+
+
+def random_state_dict(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.02) -> dict:
+    """Random-init weights with HF parameter names (no checkpoint is reachable offline)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+
+    def rn(*shape, s=std):
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * s).to(torch.bfloat16)
+
+    def ones_ish(n):
+        return (1.0 + 0.02 * torch.randn(n, generator=g, device=device)).to(torch.bfloat16)
+
+    sd = {}
+    D, H = cfg.embed_dim, cfg.hidden
+    v = "model.visual."
+    sd[v + "patch_embed.proj.weight"] = rn(D, 3, cfg.tps, cfg.patch_size, cfg.patch_size)
+    for l in range(cfg.depth):
+        b = f"{v}blocks.{l}."
+        sd[b + "norm1.weight"], sd[b + "norm1.bias"] = ones_ish(D), rn(D)
+        sd[b + "norm2.weight"], sd[b + "norm2.bias"] = ones_ish(D), rn(D)
+        sd[b + "attn.qkv.weight"], sd[b + "attn.qkv.bias"] = rn(3 * D, D), rn(3 * D)
+        sd[b + "attn.proj.weight"], sd[b + "attn.proj.bias"] = rn(D, D), rn(D)
+        sd[b + "mlp.fc1.weight"], sd[b + "mlp.fc1.bias"] = rn(cfg.mlp_dim, D), rn(cfg.mlp_dim)
+        sd[b + "mlp.fc2.weight"], sd[b + "mlp.fc2.bias"] = rn(D, cfg.mlp_dim), rn(D)
+    MD = D * cfg.merge ** 2
+    sd[v + "merger.ln_q.weight"], sd[v + "merger.ln_q.bias"] = ones_ish(D), rn(D)
+    sd[v + "merger.mlp.0.weight"], sd[v + "merger.mlp.0.bias"] = rn(MD, MD), rn(MD)
+    sd[v + "merger.mlp.2.weight"], sd[v + "merger.mlp.2.bias"] = rn(H, MD), rn(H)
+    t = "model.language_model."
+    sd[t + "embed_tokens.weight"] = rn(cfg.vocab, H)
+    for l in range(cfg.layers):
+        p = f"{t}layers.{l}."
+        sd[p + "input_layernorm.weight"] = ones_ish(H)
+        sd[p + "post_attention_layernorm.weight"] = ones_ish(H)
+        sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"] = rn(cfg.q_heads * HD, H), rn(cfg.q_heads * HD)
+        sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"] = rn(cfg.kv_heads * HD, H), rn(cfg.kv_heads * HD)
+        sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"] = rn(cfg.kv_heads * HD, H), rn(cfg.kv_heads * HD)
+        sd[p + "self_attn.o_proj.weight"] = rn(H, cfg.q_heads * HD)
+        sd[p + "mlp.gate_proj.weight"] = rn(cfg.inter, H)
+        sd[p + "mlp.up_proj.weight"] = rn(cfg.inter, H)
+        sd[p + "mlp.down_proj.weight"] = rn(H, cfg.inter)
+    sd[t + "norm.weight"] = ones_ish(H)
+    if not cfg.tie:
+        sd["lm_head.weight"] = rn(cfg.vocab, H)
+    return sd
+
+
+def normalize_keys(sd: dict) -> dict:
+    """Accept both checkpoint layouts: `visual.* / model.*` (original release) and `model.visual.* /
+    model.language_model.*` (transformers >= 4.52)."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("visual."):
+            k = "model." + k
+        elif k.startswith("model.") and not k.startswith(("model.visual.", "model.language_model.")):
+            k = "model.language_model." + k[len("model."):]
+        out[k] = v
+    return out
+
+
+def load_checkpoint_dir(path: str, device="cuda") -> tuple[ModelConfig, dict]:
+    """Load config.json + *.safetensors of a Qwen2-VL checkpoint directory (safetensors only; nothing is unpickled)."""
+    from safetensors.torch import load_file
+
+    with open(os.path.join(path, "config.json")) as f:
+        hf = json.load(f)
+    vc = hf.get("vision_config", {})
+    tc = hf.get("text_config", hf)
+    rope = tc.get("rope_parameters") or tc.get("rope_scaling") or {}
+    cfg = ModelConfig(
+        name=os.path.basename(path.rstrip("/")), depth=vc.get("depth", 32), embed_dim=vc.get("embed_dim", 1280),
+        num_heads=vc.get("num_heads", 16), mlp_ratio=vc.get("mlp_ratio", 4), patch_size=vc.get("patch_size", 14),
+        merge=vc.get("spatial_merge_size", 2), tps=vc.get("temporal_patch_size", 2), hidden=tc["hidden_size"],
+        layers=tc["num_hidden_layers"], q_heads=tc["num_attention_heads"], kv_heads=tc["num_key_value_heads"],
+        inter=tc["intermediate_size"], vocab=tc["vocab_size"], rope_theta=rope.get("rope_theta", tc.get("rope_theta", 1e6)),
+        mrope_section=tuple(rope.get("mrope_section", (16, 24, 24))), eps=tc.get("rms_norm_eps", 1e-6),
+        tie=bool(hf.get("tie_word_embeddings", tc.get("tie_word_embeddings", False))),
+        image_token_id=hf.get("image_token_id", 151655), vision_start_id=hf.get("vision_start_token_id", 151652),
+        vision_end_id=hf.get("vision_end_token_id", 151653))
+    sd = {}
+    for fn in sorted(os.listdir(path)):
+        if fn.endswith(".safetensors"):
+            sd.update(load_file(os.path.join(path, fn)))
+    sd = {k: v.to(device=device, dtype=torch.bfloat16) for k, v in normalize_keys(sd).items()}
+    return cfg, sd
+
+
+def _ceil(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class ReadEngine:
+    def __init__(self, cfg: ModelConfig, state_dict: dict, max_reads: int = 96, ctx: int = 2048, device: str = "cuda:0",
+                 vit_batch: int = 8, prefill_batch: int = 16, attn_splits: int = 0):
+        cfg.validate()
+        if not torch.cuda.is_available():
+            raise _lib.HwocrError("ReadEngine needs an MI355X (ROCm) device: there is no CPU path")
+        if max_reads < 1 or max_reads > 128:
+            raise ValueError("max_reads must be in 1..128 (one decode batch)")
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        torch.cuda.set_device(self.dev)
+        self.lib = _lib.hip()
+        self.max_reads = max_reads
+        self.ctx = _ceil(ctx, 64)
+        self.vit_batch = vit_batch
+        self.prefill_batch = prefill_batch
+        self.attn_splits = attn_splits
+        self._keep = []  # everything the C structs point at
+        self._graphs = {}
+        self._bind_weights(normalize_keys(state_dict))
+        self._alloc_state()
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _t(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.to(device=self.dev, dtype=torch.bfloat16).contiguous()
+        self._keep.append(x)
+        return x
+
+    def _bind_weights(self, sd: dict) -> None:
+        c = self.cfg
+        P = _lib.ptr
+        v = "model.visual."
+        D = c.embed_dim
+        pw = torch.zeros(D, c.kpad, dtype=torch.bfloat16, device=self.dev)
+        pw[:, : c.patch_k] = sd[v + "patch_embed.proj.weight"].reshape(D, -1).to(self.dev, torch.bfloat16)
+        self._keep.append(pw)
+        blocks = (_lib.VitBlock * c.depth)()
+        for l in range(c.depth):
+            b = f"{v}blocks.{l}."
+            for fld, key in (("ln1_w", "norm1.weight"), ("ln1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
+                             ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
+                             ("ln2_w", "norm2.weight"), ("ln2_b", "norm2.bias"), ("fc1_w", "mlp.fc1.weight"),
+                             ("fc1_b", "mlp.fc1.bias"), ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias")):
+                setattr(blocks[l], fld, P(self._t(sd[b + key])))
+        # vision rotary table, fp32, exactly as the library builds it (positions * inv_freq, then cos/sin)
+        hd = c.vit_hd
+        inv = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float) / (hd // 2)))
+        ang = torch.arange(512, dtype=torch.float).unsqueeze(-1) * inv
+        self.vit_cos = ang.cos().contiguous().to(self.dev)
+        self.vit_sin = ang.sin().contiguous().to(self.dev)
+        self.lut = torch.from_numpy(imageproc.pixel_lut()).to(torch.bfloat16).to(self.dev)
+        self.vit = _lib.Vit(depth=c.depth, dim=D, heads=c.num_heads, mlp_dim=c.mlp_dim, patch=c.patch_size, merge=c.merge,
+                            tps=c.tps, kpad=c.kpad, out_dim=c.hidden, eps=1e-6, patch_w=P(pw), blocks=blocks,
+                            merger_ln_w=P(self._t(sd[v + "merger.ln_q.weight"])), merger_ln_b=P(self._t(sd[v + "merger.ln_q.bias"])),
+                            merger_fc1_w=P(self._t(sd[v + "merger.mlp.0.weight"])), merger_fc1_b=P(self._t(sd[v + "merger.mlp.0.bias"])),
+                            merger_fc2_w=P(self._t(sd[v + "merger.mlp.2.weight"])), merger_fc2_b=P(self._t(sd[v + "merger.mlp.2.bias"])),
+                            rope_cos=P(self.vit_cos), rope_sin=P(self.vit_sin), pixel_lut=P(self.lut))
+        self._keep.append(blocks)
+
+        t = "model.language_model."
+        layers = (_lib.DecLayer * c.layers)()
+        for l in range(c.layers):
+            p = f"{t}layers.{l}."
+            qkv_w = torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"],
+                               sd[p + "self_attn.v_proj.weight"]], dim=0)
+            qkv_b = torch.cat([sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"],
+                               sd[p + "self_attn.v_proj.bias"]], dim=0)
+            # gate/up rows interleaved in 16-row tiles so one MFMA tile pair yields silu(gate)*up (csrc/gemm.hip)
+            g = sd[p + "mlp.gate_proj.weight"].reshape(c.inter // 16, 16, c.hidden)
+            u = sd[p + "mlp.up_proj.weight"].reshape(c.inter // 16, 16, c.hidden)
+            gu = torch.stack([g, u], dim=1).reshape(2 * c.inter, c.hidden)
+            L = layers[l]
+            L.in_norm_w = P(self._t(sd[p + "input_layernorm.weight"]))
+            L.qkv_w, L.qkv_b = P(self._t(qkv_w)), P(self._t(qkv_b))
+            L.o_w = P(self._t(sd[p + "self_attn.o_proj.weight"]))
+            L.post_norm_w = P(self._t(sd[p + "post_attention_layernorm.weight"]))
+            L.gate_up_w = P(self._t(gu))
+            L.down_w = P(self._t(sd[p + "mlp.down_proj.weight"]))
+        embed = self._t(sd[t + "embed_tokens.weight"])
+        head = embed if (c.tie or "lm_head.weight" not in sd) else self._t(sd["lm_head.weight"])
+        inv = 1.0 / (c.rope_theta ** (torch.arange(0, HD, 2, dtype=torch.float) / HD))
+        ang = torch.arange(max(self.ctx + 64, 4096), dtype=torch.float).unsqueeze(-1) * inv
+        self.dec_cos = ang.cos().to(torch.bfloat16).contiguous().to(self.dev)
+        self.dec_sin = ang.sin().to(torch.bfloat16).contiguous().to(self.dev)
+        self.max_pos = ang.shape[0]
+        self.dec = _lib.Decoder(layers=c.layers, hidden=c.hidden, Hq=c.q_heads, Hkv=c.kv_heads, inter=c.inter, vocab=c.vocab,
+                                sec0=c.mrope_section[0], sec1=c.mrope_section[0] + c.mrope_section[1], eps=c.eps,
+                                embed=P(embed), lm_head=P(head), final_norm_w=P(self._t(sd[t + "norm.weight"])), L=layers,
+                                rope_cos=P(self.dec_cos), rope_sin=P(self.dec_sin))
+        self._keep.append(layers)
+        self.embed_weight = embed
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def _alloc_state(self) -> None:
+        c, R, dev = self.cfg, self.max_reads, self.dev
+        bf = torch.bfloat16
+        kv_elems = c.layers * R * c.kv_heads * self.ctx * HD
+        self.k_cache = torch.zeros(kv_elems, dtype=bf, device=dev)
+        self.vt_cache = torch.zeros(kv_elems, dtype=bf, device=dev)
+        self.kv = _lib.Kv(k=_lib.ptr(self.k_cache), vt=_lib.ptr(self.vt_cache), nseq_max=R, ctx=self.ctx)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.cur_ids = torch.zeros(R, **i32)
+        self.lens = torch.zeros(R, **i32)
+        self.n_gen = torch.zeros(R, **i32)
+        self.finished = torch.zeros(R, **i32)
+        self.rope_delta = torch.zeros(R, **i32)
+        self.out_tokens = None
+        self._tok_bufs = {}
+        self._ws_dec = None
+        self._ws_rows = 0
+        self._vit_rows = 0
+
+    def _dec_ws(self, rows: int) -> _lib.DecWs:
+        """Workspace for prefill (rows = reads x padded prompt length) and decode (rows = reads)."""
+        c, dev, bf = self.cfg, self.dev, torch.bfloat16
+        if self._ws_dec is None or rows > self._ws_rows:
+            R = self.max_reads
+            QW = (c.q_heads + 2 * c.kv_heads) * HD
+            slab_elems = 40 * R * max(QW, c.hidden)  # split-K never exceeds ceil(K/256) <= 35 slices here
+            splits = 16
+            self._bufs = dict(
+                h=torch.empty(rows, c.hidden, dtype=bf, device=dev), hn=torch.empty(rows, c.hidden, dtype=bf, device=dev),
+                qkv=torch.empty(rows, QW, dtype=bf, device=dev), q=torch.empty(rows, c.q_heads * HD, dtype=bf, device=dev),
+                attn=torch.empty(rows, c.q_heads * HD, dtype=bf, device=dev), act=torch.empty(rows, c.inter, dtype=bf, device=dev),
+                slabs=torch.empty(slab_elems, dtype=torch.float32, device=dev),
+                part_o=torch.empty(R * c.q_heads * splits * HD, dtype=torch.float32, device=dev),
+                part_ml=torch.empty(R * c.q_heads * splits * 2, dtype=torch.float32, device=dev),
+                logits=torch.empty(R, c.vocab, dtype=bf, device=dev))
+            self._ws_rows = rows
+            self._ws_dec = _lib.DecWs(**{k: _lib.ptr(v) for k, v in self._bufs.items()})
+            self._drop_graphs()  # graphs bake workspace pointers
+        return self._ws_dec
+
+    def _vit_ws(self, rows: int) -> _lib.VitWs:
+        c, dev, bf = self.cfg, self.dev, torch.bfloat16
+        if rows > self._vit_rows:
+            D, hd = c.embed_dim, c.vit_hd
+            mm = c.merge ** 2
+            self._vbufs = dict(
+                patches=torch.zeros(rows, c.kpad, dtype=bf, device=dev), x=torch.empty(rows, D, dtype=bf, device=dev),
+                xn=torch.empty(rows, D, dtype=bf, device=dev), qkv=torch.empty(rows, 3 * D, dtype=bf, device=dev),
+                q=torch.empty(rows * D, dtype=bf, device=dev), k=torch.empty(rows * D, dtype=bf, device=dev),
+                vt=torch.zeros(rows * D, dtype=bf, device=dev), attn=torch.empty(rows, D, dtype=bf, device=dev),
+                mlp=torch.empty(rows, c.mlp_dim, dtype=bf, device=dev),
+                merge_mid=torch.empty(rows // mm, D * mm, dtype=bf, device=dev))
+            self._vit_rows = rows
+            self._vws = _lib.VitWs(**{k: _lib.ptr(v) for k, v in self._vbufs.items()})
+            self._vit_layout = None
+        return self._vws
+
+    def _drop_graphs(self) -> None:
+        for g in self._graphs.values():
+            self.lib.hwocr_decode_graph_destroy(g)
+        self._graphs = {}
+
+    def close(self) -> None:
+        self._drop_graphs()
+
+    # ------------------------------------------------------------------------------------------ vision tower
+    def encode_pages(self, pages: list[np.ndarray]) -> tuple[torch.Tensor, list[tuple[int, int, int]], list[int]]:
+        """uint8 [H, W, 3] pages already at tower resolution -> (embeddings [sum rows][hidden], grids, first row of
+        each page in the embedding buffer).  Pages of equal size are batched `vit_batch` at a time."""
+        c = self.cfg
+        st = _lib.stream_handle()
+        mm = c.merge ** 2
+        grids = [(1, p.shape[0] // c.patch_size, p.shape[1] // c.patch_size) for p in pages]
+        first = [0] * len(pages)
+        chunks = []
+        total = 0
+        by_shape: dict = {}
+        for i, p in enumerate(pages):
+            by_shape.setdefault(p.shape[:2], []).append(i)
+        for (H, W), idxs in by_shape.items():
+            gh, gw = H // c.patch_size, W // c.patch_size
+            P = gh * gw
+            Pp = _ceil(P, 64)
+            ph, pw = imageproc.vision_positions(gh, gw, c.merge)
+            for s in range(0, len(idxs), self.vit_batch):
+                group = idxs[s: s + self.vit_batch]
+                n = len(group)
+                rows = n * Pp
+                ws = self._vit_ws(_ceil(self.vit_batch * Pp, 64))
+                layout = (n, Pp, gh, gw)
+                if self._vit_layout != layout:
+                    # per-layout index tables; pad rows keep zero patches and position 0
+                    hh = np.zeros(rows, np.int32)
+                    wwp = np.zeros(rows, np.int32)
+                    for j in range(n):
+                        hh[j * Pp: j * Pp + P], wwp[j * Pp: j * Pp + P] = ph, pw
+                    self._pos_h = torch.from_numpy(hh).to(self.dev)
+                    self._pos_w = torch.from_numpy(wwp).to(self.dev)
+                    self._seg = torch.full((n,), P, dtype=torch.int32, device=self.dev)
+                    self._vbufs["patches"].zero_()
+                    self._vit_layout = layout
+                imgs = torch.from_numpy(np.stack([pages[i] for i in group])).to(self.dev, non_blocking=True)
+                out = torch.empty(rows // mm, c.hidden, dtype=torch.bfloat16, device=self.dev)
+                _lib.check(self.lib.hwocr_vit_forward(C.byref(self.vit), C.byref(ws), _lib.ptr(imgs), n, H, W, Pp,
+                                                      _lib.ptr(self._pos_h), _lib.ptr(self._pos_w), _lib.ptr(self._seg),
+                                                      _lib.ptr(out), st), "hwocr_vit_forward")
+                self._keep_tmp = imgs
+                for j, i in enumerate(group):
+                    first[i] = total + j * (Pp // mm)
+                total += rows // mm
+                chunks.append(out)
+        emb = chunks[0] if len(chunks) == 1 else torch.cat(chunks, dim=0)
+        return emb, grids, first
+
+    # ------------------------------------------------------------------------------------------ generate
+    def generate(self, pages: list[np.ndarray], prompts: list[np.ndarray], max_new: int, min_new: int = 0,
+                 forced: np.ndarray | None = None, return_logits: bool = False, use_graph: bool = True):
+        """Greedy reads.  pages[i]: uint8 [H, W, 3] at tower resolution; prompts[i]: int32 token ids containing one run
+        of image placeholders sized for pages[i].  Returns list of generated-token lists (and, for tests, the per-step
+        logits of every read when return_logits; `forced` [R][max_new] teacher-forces the fed tokens)."""
+        c, lib, dev = self.cfg, self.lib, self.dev
+        R = len(pages)
+        if R == 0:
+            return []
+        if R > self.max_reads:
+            raise ValueError(f"{R} reads exceed max_reads={self.max_reads}")
+        st = _lib.stream_handle()
+        emb, grids, first = self.encode_pages(pages)
+        T = [len(p) for p in prompts]
+        Tp = _ceil(max(T), 64)
+        if Tp + max_new > self.ctx:
+            raise ValueError(f"prompt ({max(T)}) + max_new ({max_new}) exceeds the KV cache length {self.ctx}")
+        ids = np.zeros((R, Tp), np.int32)
+        img_row = np.full((R, Tp), -1, np.int32)
+        pos3 = np.zeros((3, R, Tp), np.int32)
+        delta = np.zeros(R, np.int32)
+        for r in range(R):
+            p = np.asarray(prompts[r], np.int32)
+            ids[r, : T[r]] = p
+            m = np.nonzero(p == c.image_token_id)[0]
+            n_img = grids[r][1] * grids[r][2] // c.merge ** 2
+            if len(m) != n_img:
+                raise ValueError(f"read {r}: {len(m)} image placeholders but the page yields {n_img} image tokens")
+            img_row[r, m] = first[r] + np.arange(n_img, dtype=np.int32)
+            pos3[:, r, : T[r]], delta[r] = imageproc.mrope_positions(p, c.image_token_id, [grids[r]], c.merge)
+        if int(pos3.max()) + max_new + 2 > self.max_pos:
+            raise ValueError("rope table too short for this prompt")
+        d_ids = torch.from_numpy(ids).to(dev)
+        d_img = torch.from_numpy(img_row).to(dev)
+        d_pos = torch.from_numpy(pos3).to(dev)
+        lens_h = torch.tensor(T, dtype=torch.int32)
+        d_seq = lens_h.to(dev)
+        self.lens[:R].copy_(d_seq)
+        self.rope_delta[:R].copy_(torch.from_numpy(delta).to(dev))
+        self.n_gen[:R].zero_()
+        self.finished[:R].zero_()
+        if max_new not in self._tok_bufs:  # stable address per max_new: captured graphs write into it
+            self._tok_bufs[max_new] = torch.empty((self.max_reads, max_new), dtype=torch.int32, device=dev)
+        self.out_tokens = self._tok_bufs[max_new]
+        self.out_tokens.fill_(c.pad_id)
+        eos = (C.c_int * 4)(*(list(c.eos_ids) + [0] * 4)[:4])
+        gs = _lib.GenState(cur_ids=_lib.ptr(self.cur_ids), lens=_lib.ptr(self.lens), n_gen=_lib.ptr(self.n_gen),
+                           finished=_lib.ptr(self.finished), out_tokens=_lib.ptr(self.out_tokens),
+                           rope_delta=_lib.ptr(self.rope_delta), max_new=max_new, min_new=min_new,
+                           n_eos=min(len(c.eos_ids), 4), pad_id=c.pad_id, eos=eos)
+        pb = min(self.prefill_batch, R)
+        ws = self._dec_ws(max(pb * Tp, self.max_reads))
+        step_logits = [] if return_logits else None
+        first_logits = []
+        for s0 in range(0, R, pb):
+            n = min(pb, R - s0)
+            last = torch.tensor([j * Tp + T[s0 + j] - 1 for j in range(n)], dtype=torch.int32, device=dev)
+            pos_chunk = d_pos[:, s0: s0 + n].contiguous()
+            _lib.check(lib.hwocr_prefill(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs),
+                                         _lib.ptr(d_ids[s0: s0 + n]), _lib.ptr(d_img[s0: s0 + n]), _lib.ptr(emb),
+                                         _lib.ptr(pos_chunk), _lib.ptr(d_seq[s0: s0 + n]), _lib.ptr(last), n, Tp, s0,
+                                         max(T[s0: s0 + n]), st), "hwocr_prefill")
+            if return_logits:
+                first_logits.append(self._bufs["logits"][:n].clone())
+            torch.cuda.current_stream().synchronize()  # the chunk's index tensors die with this iteration
+        if return_logits:
+            step_logits.append(torch.cat(first_logits, dim=0))
+        if forced is not None:
+            self.cur_ids[:R].copy_(torch.from_numpy(np.ascontiguousarray(forced[:, 0]).astype(np.int32)).to(dev))
+        splits = self.attn_splits or max(1, min(16, 512 // max(1, R * c.kv_heads)))
+        steps = max_new - 1
+        if use_graph and not return_logits and forced is None and steps > 0:
+            key = (R, splits, max_new, min_new)
+            if key not in self._graphs:
+                # one eager step first: lazy one-time kernel attributes must not be set inside a capture
+                _lib.check(lib.hwocr_decode_step(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs), R, splits, st))
+                steps -= 1
+                torch.cuda.current_stream().synchronize()
+                g = C.c_void_p()
+                self._gs_keep = (gs, eos)
+                _lib.check(lib.hwocr_decode_graph_create(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs), R,
+                                                         splits, C.byref(g)), "hwocr_decode_graph_create")
+                self._graphs[key] = g
+            done = 0
+            while done < steps:
+                n = min(32, steps - done)
+                _lib.check(lib.hwocr_decode_graph_launch(self._graphs[key], n, st), "hwocr_decode_graph_launch")
+                done += n
+                if min_new < max_new and bool(self.finished[:R].all()):
+                    break
+        else:
+            for i in range(steps):
+                _lib.check(lib.hwocr_decode_step(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs), R, splits, st))
+                if return_logits:
+                    step_logits.append(self._bufs["logits"][:R].clone())
+                if forced is not None and i + 1 < max_new:
+                    self.cur_ids[:R].copy_(torch.from_numpy(np.ascontiguousarray(forced[:, i + 1]).astype(np.int32)).to(dev))
+        torch.cuda.current_stream().synchronize()
+        toks = self.out_tokens[:R].cpu().numpy()
+        ng = self.n_gen[:R].cpu().numpy()
+        out = []
+        for r in range(R):
+            seq = toks[r, : min(int(ng[r]), max_new)].tolist()
+            # drop what follows the first EOS (finished reads keep emitting pad in lockstep)
+            for k, t in enumerate(seq):
+                if t in c.eos_ids and k + 1 >= min_new:
+                    seq = seq[: k + 1]
+                    break
+            out.append(seq)
+        if return_logits:
+            return out, torch.stack(step_logits, dim=1)  # [R][steps][V]
+        return out

@@ -1,0 +1,121 @@
+"""Drop-in surface of the page-read path: the names `ocr_agent/nodes.py:8-14` imports from `ocr_agent.tools`
+(compare_versions, merge_versions, preprocess_image, run_ocr, unload_ocr_model) with the reference's signatures,
+prints and singleton semantics, plus the pass-through names of the same module.
+
+    run_ocr(image_path, params=None) -> str      ocr_agent/tools.py:728-771
+    _load_ocr_model() -> (model, processor)      ocr_agent/tools.py:683-711   (process-global, lazily built)
+    unload_ocr_model() -> None                   ocr_agent/tools.py:714-725
+
+Differences, all behind the same calls: the model is the MI355X read engine (no CPU / other-device path: without the
+HIP library or a GPU `run_ocr` raises), and `unload_ocr_model()` keeps the weights resident unless
+HWOCR_KEEP_RESIDENT=0 — the reference drops them after every node so Ollama fits on a 48 GB laptop, which on a
+288 GB MI355X only buys a checkpoint reload per re-read.  `run_ocr_batch` is the batched entry the reference lacks.
+
+Model selection: HWOCR_MODEL = a checkpoint directory (config.json + *.safetensors [+ tokenizer.json]) or a preset
+name ("qwen2-vl-2b", "small", "tiny"); presets are random-init because no checkpoint is reachable offline.
+"""
+from __future__ import annotations
+
+import gc
+import os
+from pathlib import Path
+
+from PIL import Image
+
+from .compat import config
+from .preprocess import preprocess_image  # noqa: F401  (re-exported)
+from .text import (_align_to_backbone, _find_differing_segments, _levenshtein_words, cer, compare_versions,  # noqa: F401
+                   evaluate, levenshtein, merge_versions, normalize_text, parse_ground_truth, parse_json_response,
+                   tier1_metrics, wer)
+
+_ocr_model = None
+_ocr_processor = None
+
+
+def _load_ocr_model():
+    global _ocr_model, _ocr_processor
+    if _ocr_model is not None:
+        return _ocr_model, _ocr_processor
+    import torch
+
+    from . import _lib, engine, tokenizer
+
+    if not torch.cuda.is_available():
+        raise _lib.HwocrError("run_ocr needs an MI355X: the read engine has no CPU path")
+    spec = os.environ.get("HWOCR_MODEL", "qwen2-vl-2b")
+    print(f"  [ocr] Loading {spec} on cuda...")
+    if os.path.isdir(spec):
+        cfg, sd = engine.load_checkpoint_dir(spec)
+        tok = (tokenizer.HFTokenizer(cfg, spec) if os.path.exists(os.path.join(spec, "tokenizer.json"))
+               else tokenizer.ByteTokenizer(cfg))
+    else:
+        cfg = engine.preset(spec)
+        print("  [ocr] (no checkpoint directory given: random-init weights, byte-level tokenizer)")
+        sd = engine.random_state_dict(cfg, seed=int(os.environ.get("HWOCR_SEED", "0")))
+        tok = tokenizer.ByteTokenizer(cfg, fold_unknown=True)
+    cfg.min_pixels, cfg.max_pixels = config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS
+    _ocr_model = engine.ReadEngine(cfg, sd, max_reads=int(os.environ.get("HWOCR_MAX_READS", "96")),
+                                   ctx=int(os.environ.get("HWOCR_CTX", "4096")))
+    _ocr_processor = tokenizer.Processor(cfg, tok)
+    print("  [ocr] Model loaded.")
+    return _ocr_model, _ocr_processor
+
+
+def unload_ocr_model():
+    global _ocr_model, _ocr_processor
+    if os.environ.get("HWOCR_KEEP_RESIDENT", "1") == "0" and _ocr_model is not None:
+        _ocr_model.close()
+        _ocr_model = None
+        _ocr_processor = None
+        gc.collect()
+        import torch
+
+        torch.cuda.empty_cache()
+    print("  [ocr] Model unloaded, memory freed.")
+
+
+def run_ocr_batch(images: list, params: dict | None = None) -> list[str]:
+    """Read many (already preprocessed) pages in one engine batch.  `images`: paths or PIL images."""
+    params = params or {}
+    model, processor = _load_ocr_model()
+    prompt = params.get("prompt", config.OCR_PROMPT)
+    max_new = params.get("max_new_tokens", config.OCR_MAX_NEW_TOKENS)
+    min_new = params.get("min_new_tokens", 0)
+    texts: list[str] = []
+    for s in range(0, len(images), model.max_reads):
+        pages, prompts = [], []
+        for im in images[s: s + model.max_reads]:
+            img = im if isinstance(im, Image.Image) else Image.open(im)
+            page, ids = processor.prepare(img, prompt)
+            pages.append(page)
+            prompts.append(ids)
+        for toks in model.generate(pages, prompts, max_new=max_new, min_new=min_new):
+            texts.append(processor.decode(toks, skip_special_tokens=True))
+    return texts
+
+
+def run_ocr(image_path: str, params: dict | None = None) -> str:
+    print(f"  [ocr] Running OCR on {Path(image_path).name}...")
+    result = run_ocr_batch([str(image_path)], params)[0]
+    print(f"  [ocr] Done ({len(result)} chars)")
+    return result
+
+
+_PATCHED = ("compare_versions", "merge_versions", "preprocess_image", "run_ocr", "unload_ocr_model", "_load_ocr_model",
+            "levenshtein", "_levenshtein_words", "cer", "wer", "tier1_metrics", "normalize_text")
+
+
+def install() -> None:
+    """Bind this module's functions into an installed reference package: `ocr_agent.tools` always, and `ocr_agent.nodes`
+    too when it has already been imported (it copies the names at import time, nodes.py:8-14)."""
+    import importlib
+    import sys
+
+    ref_tools = importlib.import_module("ocr_agent.tools")
+    me = sys.modules[__name__]
+    for name in _PATCHED:
+        setattr(ref_tools, name, getattr(me, name))
+    nodes = sys.modules.get("ocr_agent.nodes")
+    if nodes is not None:
+        for name in ("compare_versions", "merge_versions", "preprocess_image", "run_ocr", "unload_ocr_model"):
+            setattr(nodes, name, getattr(me, name))

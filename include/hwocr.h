@@ -167,6 +167,10 @@ int hwocr_decode_graph_create(const hwocr_decoder* m, const hwocr_dec_ws* ws, co
 int hwocr_decode_graph_launch(void* graph, int n, hwocr_stream_t stream);
 int hwocr_decode_graph_destroy(void* graph);
 
+/* bench instrumentation: HIP events on the launch stream around every hwocr_gemm_wide launch while enabled */
+int hwocr_profile_enable(int on);
+int hwocr_profile_read(double* total_ms, double* total_flops, long* launches);
+
 /* ---- native text kernels (libhwocr_text.so, host C++) ------------------------------------------------------- */
 
 /* unit-cost edit distance over code points / word ids; replaces tools.py:69-100 */

@@ -1,0 +1,109 @@
+"""Model-level parity on the MI355X: the read engine (vision tower -> prefill -> graph-captured decode) on the tiny
+seeded Qwen2-VL of tests/golden against (1) the outputs of the real HF classes stored there and (2) the CPU oracle.
+
+Tolerances (the reference states none): bf16 engine vs HF bf16 — teacher-forced logits max-abs
+<= 3e-2 x logit scale, top-1 agreement on every step whose HF top-1/top-2 margin exceeds 0.05."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+from tests._golden import tiny_case, tiny_meta, tiny_ref_config, tiny_weights  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from handwritten_ocr_amd import engine
+
+    cfg = engine.preset("tiny")
+    e = engine.ReadEngine(cfg, tiny_weights(torch.bfloat16), max_reads=8, ctx=256, vit_batch=2, prefill_batch=2)
+    yield e
+    e.close()
+
+
+def _page(eng, g, case):
+    from handwritten_ocr_amd import imageproc
+
+    c = eng.cfg
+    return imageproc.prepare_page(Image.fromarray(g[f"{case}.page"].numpy(), "RGB"), c.patch_size, c.merge, c.min_pixels,
+                                  c.max_pixels)
+
+
+def test_vision_tower_matches_hf(eng):
+    g = tiny_case("bf16")
+    for case in ("a", "b"):
+        page = _page(eng, g, case)
+        emb, grids, first = eng.encode_pages([page])
+        torch.cuda.synchronize()
+        want = g[f"{case}.merger"].float()
+        assert list(grids[0]) == tiny_meta()["cases"][case]["grid_thw"]
+        got = emb[first[0]: first[0] + want.shape[0]].float().cpu()
+        scale = float(want.abs().max())
+        # 2 bf16 ulps at the tensor's scale: blocking / accumulation order differ from the CPU library
+        assert float((got - want).abs().max()) <= 2 * 2 ** -7 * scale, float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_teacher_forced_logits_match_hf(eng, batched):
+    g = tiny_case("bf16")
+    meta = tiny_meta()["cases"]
+    cases = ["a", "b"] if batched else ["a"]
+    pages = [_page(eng, g, c) for c in cases]
+    prompts = [g[f"{c}.input_ids"].numpy() for c in cases]
+    n = meta["a"]["n_new"]
+    forced = np.stack([g[f"{c}.greedy_tokens"].numpy() for c in cases])
+    toks, logits = eng.generate(pages, prompts, max_new=n, min_new=n, forced=forced, return_logits=True)
+    for r, c in enumerate(cases):
+        want = g[f"{c}.step_logits"].float()
+        got = logits[r].float().cpu()
+        scale = max(1.0, float(want.abs().max()))
+        diff = float((got - want).abs().max())
+        assert diff <= 3e-2 * scale, f"case {c}: teacher-forced logits differ by {diff} (scale {scale})"
+        top2 = want.topk(2, -1).values
+        decisive = (top2[:, 0] - top2[:, 1]) > 0.05
+        hf = g[f"{c}.greedy_tokens"].tolist()
+        agree = torch.tensor([a == b for a, b in zip(toks[r], hf)])
+        assert bool(agree[decisive].all()), (toks[r], hf)
+
+
+def test_graph_decode_equals_eager_and_oracle(eng):
+    from oracle.qwen2vl_ref import Qwen2VLRef
+
+    g = tiny_case("bf16")
+    meta = tiny_meta()["cases"]
+    cases = ["a", "b", "a"]
+    pages = [_page(eng, g, c) for c in cases]
+    prompts = [g[f"{c}.input_ids"].numpy() for c in cases]
+    n = 16
+    eager = eng.generate(pages, prompts, max_new=n, min_new=n, use_graph=False)
+    graph1 = eng.generate(pages, prompts, max_new=n, min_new=n, use_graph=True)   # builds the graph
+    graph2 = eng.generate(pages, prompts, max_new=n, min_new=n, use_graph=True)   # replays it
+    assert eager == graph1 == graph2
+    assert eager[0] == eager[2], "identical reads in one batch must give identical token streams"
+    # free-running oracle (CPU bf16): must agree until the first step where the oracle's own margin is small
+    ref = Qwen2VLRef(tiny_ref_config(), tiny_weights(torch.bfloat16))
+    for r, c in enumerate(cases[:2]):
+        rt, rl = ref.generate(g[f"{c}.input_ids"].long(), g[f"{c}.pixel_values"], [tuple(meta[c]["grid_thw"])], n, n)
+        top2 = rl.float().topk(2, -1).values
+        margin = (top2[:, 0] - top2[:, 1])
+        for k in range(n):
+            if margin[k] <= 0.05:
+                break
+            assert eager[r][k] == rt[k], f"read {r} step {k}: engine {eager[r][k]} oracle {rt[k]}"
+
+
+def test_eos_stops_a_read(eng):
+    g = tiny_case("bf16")
+    page, prompt = _page(eng, g, "a"), g["a.input_ids"].numpy()
+    free = eng.generate([page], [prompt], max_new=12, min_new=12, use_graph=False)[0]
+    # declare the 4th generated token to be EOS: generation must stop right after emitting it
+    old = eng.cfg.eos_ids
+    eng.cfg.eos_ids = (free[3],)
+    try:
+        out = eng.generate([page], [prompt], max_new=12, min_new=0, use_graph=False)[0]
+    finally:
+        eng.cfg.eos_ids = old
+    first = free.index(free[3])
+    assert out == free[: first + 1]

@@ -27,6 +27,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
 
@@ -136,27 +138,7 @@ def make_text(tools) -> None:
 
 
 # ------------------------------------------------------------------------------------------------ synthetic pages
-def make_page(seed: int, h: int, w: int, ruled: bool = True) -> np.ndarray:
-    """Synthetic handwritten page: bright noisy paper, dark stroke polylines, optional ruled lines."""
-    from PIL import Image, ImageDraw
-
-    rng = np.random.default_rng(seed)
-    paper = rng.integers(200, 256, size=(h, w, 1), dtype=np.uint8).repeat(3, axis=2)
-    img = Image.fromarray(paper, "RGB")
-    d = ImageDraw.Draw(img)
-    nlines = max(2, h // 42)
-    for i in range(nlines):
-        y0 = int((i + 0.6) * h / nlines)
-        if ruled:
-            d.line([(0, y0 + 6), (w, y0 + 6)], fill=(150, 170, 210), width=1)
-        x = int(rng.integers(4, 12))
-        while x < w - 8:
-            n = int(rng.integers(3, 7))
-            pts = [(x + int(rng.integers(0, 10)) + 4 * k, y0 + int(rng.integers(-9, 7))) for k in range(n)]
-            ink = int(rng.integers(0, 81))
-            d.line(pts, fill=(ink, ink, ink), width=int(rng.integers(2, 5)))
-            x += 4 * n + int(rng.integers(6, 18))
-    return np.asarray(img)
+from handwritten_ocr_amd.synth import make_page  # noqa: E402  (same generator the bench uses)
 
 
 def make_preprocess(tools) -> None:
