@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""Headline benchmark: handwritten pages/sec (1024x1024 page, 3 preprocessing-strategy reads each) on MI355X.
+
+One "step" = one pass of the read path over one batch of synthetic pages on every rank:
+    3 strategy reads per page -> vision tower -> prefill -> N_out greedy tokens per read (min_new == max_new, so the
+    work is fixed: random-init logits otherwise hit EOS at once) -> gather token streams to rank 0 -> per page
+    compare_versions(read 1, read 2) + merge_versions(all reads).
+Inputs (the strategy-preprocessed pages, resized to tower resolution, uint8) are resident in HBM before the timed
+region starts.  Weights: random init at the Qwen2-VL-2B shape (no checkpoint is reachable offline).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...     (one rank per GPU, RCCL)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+    roofline      dominant kernel = gemm_wide (bf16 MFMA): algorithmic FLOPs / HIP-event time of its launches inside
+                  the timed steps, against the 2.5 PFLOP/s dense bf16 peak
+    cpu_baseline  the CPU oracle (oracle/, a restatement of the HF arithmetic the reference runs) timed on this host on
+                  a bounded sample of the same workload and extrapolated (see `sample`)
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_prompt(cfg, n_img: int) -> np.ndarray:
+    """14 prefix ids + <vision_start> + image placeholders + <vision_end> + 16 suffix ids."""
+    rng = np.random.default_rng(0)
+    pre = rng.integers(0, 1000, size=14).tolist()
+    suf = rng.integers(0, 1000, size=16).tolist()
+    return np.asarray(pre + [cfg.vision_start_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_id] + suf, np.int32)
+
+
+def build_inputs(cfg, n_pages: int, seed0: int, reads_per_page: int, side: int, device):
+    """Synthetic pages -> strategy reads -> tower-resolution uint8 pages resident on `device`."""
+    from PIL import Image
+
+    from handwritten_ocr_amd import imageproc, preprocess, synth
+    from handwritten_ocr_amd.compat import config
+
+    strategies = config.PREPROCESSING_STRATEGIES[:reads_per_page]
+    pages = []
+    t0 = time.perf_counter()
+    for p in range(n_pages):
+        img = Image.fromarray(synth.make_page(seed0 + p, side, side), "RGB")
+        for s in strategies:
+            arr = imageproc.prepare_page(preprocess.apply_strategy(img, s, quiet=True), cfg.patch_size, cfg.merge,
+                                         config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS)
+            pages.append(torch.from_numpy(arr).to(device))
+    host_s = time.perf_counter() - t0
+    n_img = (pages[0].shape[0] // cfg.patch_size) * (pages[0].shape[1] // cfg.patch_size) // cfg.merge ** 2
+    prompts = [synthetic_prompt(cfg, n_img)] * len(pages)
+    return pages, prompts, host_s
+
+
+def cpu_baseline(cfg, side: int, n_out: int, reads_per_page: int) -> dict:
+    """The reference's CPU path, restated (oracle/) and timed on this host on a bounded sample: full Qwen2-VL-2B
+    widths, 1 and 2 layers of each stack timed and extrapolated linearly in depth, a few decode steps, strings at full
+    page length."""
+    import torch.nn.functional as F  # noqa: F401
+    from PIL import Image
+
+    from handwritten_ocr_amd import synth
+    from handwritten_ocr_amd.compat import config
+    from oracle import image_ref, text_ref
+    from oracle.qwen2vl_ref import Qwen2VLRef, RefConfig
+
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+
+    def rn(*shape):
+        return (torch.randn(*shape, generator=g) * 0.02).to(torch.bfloat16)
+
+    D, H, MD = cfg.embed_dim, cfg.hidden, cfg.embed_dim * 4
+    sd = {"model.visual.patch_embed.proj.weight": rn(D, 3, 2, 14, 14), "model.language_model.embed_tokens.weight": rn(cfg.vocab, H),
+          "model.language_model.norm.weight": torch.ones(H, dtype=torch.bfloat16),
+          "model.visual.merger.ln_q.weight": torch.ones(D, dtype=torch.bfloat16), "model.visual.merger.ln_q.bias": rn(D),
+          "model.visual.merger.mlp.0.weight": rn(MD, MD), "model.visual.merger.mlp.0.bias": rn(MD),
+          "model.visual.merger.mlp.2.weight": rn(H, MD), "model.visual.merger.mlp.2.bias": rn(H)}
+    for l in range(2):
+        b = f"model.visual.blocks.{l}."
+        sd.update({b + "norm1.weight": torch.ones(D, dtype=torch.bfloat16), b + "norm1.bias": rn(D),
+                   b + "norm2.weight": torch.ones(D, dtype=torch.bfloat16), b + "norm2.bias": rn(D),
+                   b + "attn.qkv.weight": rn(3 * D, D), b + "attn.qkv.bias": rn(3 * D), b + "attn.proj.weight": rn(D, D),
+                   b + "attn.proj.bias": rn(D), b + "mlp.fc1.weight": rn(cfg.mlp_dim, D), b + "mlp.fc1.bias": rn(cfg.mlp_dim),
+                   b + "mlp.fc2.weight": rn(D, cfg.mlp_dim), b + "mlp.fc2.bias": rn(D)})
+        p = f"model.language_model.layers.{l}."
+        sd.update({p + "input_layernorm.weight": torch.ones(H, dtype=torch.bfloat16),
+                   p + "post_attention_layernorm.weight": torch.ones(H, dtype=torch.bfloat16),
+                   p + "self_attn.q_proj.weight": rn(cfg.q_heads * 128, H), p + "self_attn.q_proj.bias": rn(cfg.q_heads * 128),
+                   p + "self_attn.k_proj.weight": rn(cfg.kv_heads * 128, H), p + "self_attn.k_proj.bias": rn(cfg.kv_heads * 128),
+                   p + "self_attn.v_proj.weight": rn(cfg.kv_heads * 128, H), p + "self_attn.v_proj.bias": rn(cfg.kv_heads * 128),
+                   p + "self_attn.o_proj.weight": rn(H, cfg.q_heads * 128), p + "mlp.gate_proj.weight": rn(cfg.inter, H),
+                   p + "mlp.up_proj.weight": rn(cfg.inter, H), p + "mlp.down_proj.weight": rn(H, cfg.inter)})
+
+    def ref(depth, layers):
+        rc = RefConfig(depth=depth, embed_dim=D, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, hidden=H, layers=layers,
+                       q_heads=cfg.q_heads, kv_heads=cfg.kv_heads, inter=cfg.inter, vocab=cfg.vocab,
+                       image_token_id=cfg.image_token_id, vision_start_id=cfg.vision_start_id,
+                       vision_end_id=cfg.vision_end_id, eos_ids=tuple(cfg.eos_ids), pad_id=cfg.pad_id)
+        return Qwen2VLRef(rc, sd)
+
+    def timed(fn, reps=1):
+        best = float("inf")
+        for _ in range(reps):
+            t = time.perf_counter()
+            out = fn()
+            best = min(best, time.perf_counter() - t)
+        return best, out
+
+    img = Image.fromarray(synth.make_page(0, side, side), "RGB")
+    t_img, (pv, grid) = timed(lambda: image_ref.pixel_values(img, config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS))
+    pvt = torch.from_numpy(pv)
+    with torch.no_grad():
+        t_v1, emb = timed(lambda: ref(1, 1).vision(pvt, [grid]))
+        t_v2, _ = timed(lambda: ref(2, 1).vision(pvt, [grid]))
+        n_img = emb.shape[0]
+        ids = torch.from_numpy(synthetic_prompt(cfg, n_img)).long()
+        T = len(ids)
+        from oracle.qwen2vl_ref import rope_index
+
+        pos3, delta = rope_index(ids, cfg.image_token_id, [grid], 2)
+        x = F.embedding(ids, sd["model.language_model.embed_tokens.weight"])
+
+        def prefill(layers):
+            r = ref(1, layers)
+            cache = [None] * layers
+            hn = r.decoder(x, pos3, cache)
+            return r, cache, r.lm_head(hn[-1:])
+
+        t_p1, (r1, c1, _) = timed(lambda: prefill(1))
+        t_p2, (r2, c2, _) = timed(lambda: prefill(2))
+        n_dec = 4
+        t_d1, _ = timed(lambda: [r1.step(5, c1, delta) for _ in range(n_dec)])
+        t_d2, _ = timed(lambda: [r2.step(5, c2, delta) for _ in range(n_dec)])
+    t_d1, t_d2 = t_d1 / n_dec, t_d2 / n_dec
+    dv, dp, dd = max(t_v2 - t_v1, 0.0), max(t_p2 - t_p1, 0.0), max(t_d2 - t_d1, 0.0)
+    t_read = t_img + (t_v1 + (cfg.depth - 1) * dv) + (t_p1 + (cfg.layers - 1) * dp) + (n_out - 1) * (t_d1 + (cfg.layers - 1) * dd)
+    rng = np.random.default_rng(1)
+    words = ["".join(chr(97 + int(c)) for c in rng.integers(0, 26, size=int(rng.integers(2, 9)))) for _ in range(260)]
+    texts = [" ".join(words)] + [" ".join(w if rng.random() > 0.1 else w[::-1] for w in words) for _ in range(2)]
+    t_str, _ = timed(lambda: (text_ref.compare_versions(texts[0], texts[1]), text_ref.merge_versions(texts)))
+    t_page = reads_per_page * t_read + t_str
+    return {"value": 1.0 / t_page, "unit": "pages/s", "cores": threads, "kind": "port",
+            "sample": (f"oracle/ (torch CPU bf16 restatement of the HF Qwen2-VL path) at full Qwen2-VL-2B widths on one "
+                       f"{side}x{side} page: image processor + vision tower / decoder prefill (T={T}) / decode step timed with "
+                       f"1 and 2 layers and extrapolated linearly to {cfg.depth}/{cfg.layers} layers; {n_dec} decode steps "
+                       f"scaled to {n_out - 1}; compare+merge of three {len(texts[0])}-char reads in pure Python; "
+                       f"x{reads_per_page} serial reads per page as nodes.py:86-110"),
+            "seconds_per_page": t_page,
+            "parts_s": {"image_processor": t_img, "vision_1layer": t_v1, "vision_per_layer": dv, "prefill_1layer": t_p1,
+                        "prefill_per_layer": dp, "decode_step_1layer": t_d1, "decode_step_per_layer": dd, "strings": t_str}}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pages", type=int, default=32, help="pages per step per GPU (x3 reads in flight)")
+    ap.add_argument("--reads", type=int, default=3)
+    ap.add_argument("--new-tokens", type=int, default=512)
+    ap.add_argument("--side", type=int, default=1024)
+    ap.add_argument("--model", default="qwen2-vl-2b")
+    ap.add_argument("--vit-batch", type=int, default=12)
+    ap.add_argument("--prefill-batch", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from handwritten_ocr_amd import _lib, engine, shard, text, tokenizer
+
+    rank, local, world = shard.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the read engine has no CPU path)")
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+
+    cfg = engine.preset(args.model)
+    n_reads = args.pages * args.reads
+    sd = engine.random_state_dict(cfg, seed=0, device=dev)
+    eng = engine.ReadEngine(cfg, sd, max_reads=n_reads, ctx=2048, device=str(dev), vit_batch=args.vit_batch,
+                            prefill_batch=args.prefill_batch)
+    del sd
+    eng.collect_timings = True
+    tok = tokenizer.ByteTokenizer(cfg, fold_unknown=True)
+    pages, prompts, host_prep_s = build_inputs(cfg, args.pages, 1000 * rank, args.reads, args.side, dev)
+    lib = _lib.hip()
+
+    def step():
+        toks = eng.generate(pages, prompts, max_new=args.new_tokens, min_new=args.new_tokens)
+        t = torch.tensor(toks, dtype=torch.int32, device=dev)
+        counts = torch.full((len(toks),), args.new_tokens, dtype=torch.int32, device=dev)
+        shard.gather_token_streams(t, counts, dst=0)
+        merged = []
+        for p in range(args.pages):
+            reads = [tok.decode(toks[p * args.reads + r]) for r in range(args.reads)]
+            if len(reads) >= 2:
+                text.compare_versions(reads[0], reads[1])
+            merged.append(text.merge_versions(reads))
+        return merged
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    phases = []
+    barrier()
+    _lib.check(lib.hwocr_profile_enable(1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        phases.append(dict(eng.timings))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms, fl, n = C.c_double(), C.c_double(), C.c_long()
+    _lib.check(lib.hwocr_profile_read(C.byref(ms), C.byref(fl), C.byref(n)))
+    lib.hwocr_profile_enable(0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    if rank != 0:
+        return
+
+    pages_total = args.pages * world * args.steps
+    value = pages_total / elapsed
+    achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    mean = lambda k: float(np.mean([p[k] for p in phases]))  # noqa: E731
+    T = len(prompts[0])
+    dec_ms = mean("decode_ms") / max(1, args.new_tokens - 1)
+    # decoder bytes per step: all layer weights + LM head (tied) + KV of every read at its mean context
+    per_layer = (cfg.q_heads + 2 * cfg.kv_heads) * 128 * cfg.hidden + cfg.q_heads * 128 * cfg.hidden + 3 * cfg.inter * cfg.hidden
+    w_bytes = 2.0 * (cfg.layers * per_layer + cfg.vocab * cfg.hidden)
+    kv_bytes = n_reads * cfg.layers * 2 * cfg.kv_heads * 128 * 2 * (T + args.new_tokens / 2)
+    out = {
+        "metric": "handwritten pages/sec (1024x1024, 3-strategy reads)", "value": value, "unit": "pages/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Qwen2-VL-2B shape (random init) x {args.side}x{args.side} synthetic handwritten pages, "
+                               f"{args.reads} preprocessing-strategy reads per page, {args.new_tokens} greedy tokens per read",
+                   "pages_per_step_per_gpu": args.pages, "reads_in_flight": n_reads, "prompt_tokens": T,
+                   "image_tokens": int((prompts[0] == cfg.image_token_id).sum()), "new_tokens": args.new_tokens,
+                   "parallelism": f"replicas x{world}, pages sharded, RCCL gather of token streams"},
+        "roofline": {"bound": "mfma", "kernel": "gemm_wide_kernel (bf16 128x128x64 MFMA GEMM)", "achieved": achieved,
+                     "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "launches": int(n.value), "avg_launch_ms": ms.value / max(1, n.value),
+                     "algorithmic_flops_per_launch": fl.value / max(1, n.value),
+                     "share_of_step_time": ms.value / (elapsed * 1e3)},
+        "phases_ms_per_step": {"vision": mean("vision_ms"), "prefill": mean("prefill_ms"), "decode": mean("decode_ms"),
+                               "decode_per_token": dec_ms},
+        "decode_roofline": {"bound": "hbm", "bytes_per_step": w_bytes + kv_bytes, "achieved": (w_bytes + kv_bytes) / (dec_ms * 1e-3) / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (w_bytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        "host_preprocess_s_per_page": host_prep_s / args.pages,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.side, args.new_tokens, args.reads)
+        except Exception as e:  # the baseline is a report, never a reason to lose the GPU measurement
+            out["cpu_baseline"] = {"value": None, "unit": "pages/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"failed: {type(e).__name__}: {e}"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

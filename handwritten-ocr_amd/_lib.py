@@ -25,7 +25,10 @@ _CODES = {1: "HWOCR_EINVAL (argument rejected by the launcher)", 2: "HWOCR_ELAUN
 
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
-        raise HwocrError(f"{what or 'hwocr call'} failed: {_CODES.get(rc, rc)}")
+        detail = ""
+        if rc == 2 and _hip is not None:
+            detail = " — " + (_hip.hwocr_last_error() or b"").decode(errors="replace")
+        raise HwocrError(f"{what or 'hwocr call'} failed: {_CODES.get(rc, rc)}{detail}")
 
 
 class VitBlock(C.Structure):
@@ -69,6 +72,7 @@ class GenState(C.Structure):
 
 _HIP_SIGS = {
     "hwocr_abi_version": ([], I),
+    "hwocr_last_error": ([], C.c_char_p),
     "hwocr_gemm_wide": ([P, P, P, P, P, I, I, I, I, I, I, I, I, P], I),
     "hwocr_gemm_skinny": ([P, P, P, P, I, I, I, I, I, I, I, I, P], I),
     "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, P], I),
@@ -118,6 +122,11 @@ def hip() -> C.CDLL:
     """The device library.  Raises if it has not been built (no fallback path exists)."""
     global _hip
     if _hip is None:
+        # torch bundles its own libamdhip64; it must be in the process BEFORE our library is loaded, otherwise the
+        # loader resolves our NEEDED libamdhip64.so.7 to the system copy and the process ends up with two HIP runtimes
+        # (streams and pointers of one are "no device" to the other).
+        import torch  # noqa: F401
+
         if not os.path.exists(_build.HIP_LIB):
             raise HwocrError(
                 f"{_build.HIP_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`; "

@@ -49,6 +49,12 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
-static inline int hwocr_launch_status() {
-  return hipGetLastError() == hipSuccess ? HWOCR_OK : HWOCR_ELAUNCH;
+// last launch failure of this process (which launcher, which HIP error): read back through hwocr_last_error()
+extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text);
+static inline int hwocr_launch_status_at(const char* where) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return HWOCR_OK;
+  hwocr_record_error(where, (int)e, hipGetErrorString(e));
+  return HWOCR_ELAUNCH;
 }
+#define hwocr_launch_status() hwocr_launch_status_at(__func__)

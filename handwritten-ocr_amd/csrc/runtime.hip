@@ -7,6 +7,7 @@
 // once into a HIP graph and replayed for every generated token without a host round trip.
 #include "common.cuh"
 #include "hwocr.h"
+#include <cstdio>
 #include <vector>
 
 #define CHECK(call)                \
@@ -33,6 +34,12 @@ inline int pick_splitk(int K, int N, int want_wgs) {
 }  // namespace
 
 extern "C" int hwocr_abi_version(void) { return 1; }
+
+static char g_last_error[256] = "";
+extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s: HIP error %d (%s)", where, hip_error, text ? text : "?");
+}
+extern "C" const char* hwocr_last_error(void) { return g_last_error; }
 
 extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, const void* images, int nimg, int H,
                                  int W, int rows_per_img_ld, const int* pos_h, const int* pos_w,

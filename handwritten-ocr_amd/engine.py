@@ -211,6 +211,8 @@ class ReadEngine:
         self.vit_batch = vit_batch
         self.prefill_batch = prefill_batch
         self.attn_splits = attn_splits
+        self.collect_timings = False
+        self.timings = {}
         self._keep = []  # everything the C structs point at
         self._graphs = {}
         self._bind_weights(normalize_keys(state_dict))
@@ -359,13 +361,13 @@ class ReadEngine:
         c = self.cfg
         st = _lib.stream_handle()
         mm = c.merge ** 2
-        grids = [(1, p.shape[0] // c.patch_size, p.shape[1] // c.patch_size) for p in pages]
+        grids = [(1, int(p.shape[0]) // c.patch_size, int(p.shape[1]) // c.patch_size) for p in pages]
         first = [0] * len(pages)
         chunks = []
         total = 0
         by_shape: dict = {}
         for i, p in enumerate(pages):
-            by_shape.setdefault(p.shape[:2], []).append(i)
+            by_shape.setdefault((int(p.shape[0]), int(p.shape[1])), []).append(i)
         for (H, W), idxs in by_shape.items():
             gh, gw = H // c.patch_size, W // c.patch_size
             P = gh * gw
@@ -388,7 +390,10 @@ class ReadEngine:
                     self._seg = torch.full((n,), P, dtype=torch.int32, device=self.dev)
                     self._vbufs["patches"].zero_()
                     self._vit_layout = layout
-                imgs = torch.from_numpy(np.stack([pages[i] for i in group])).to(self.dev, non_blocking=True)
+                if isinstance(pages[group[0]], torch.Tensor):  # already resident in HBM
+                    imgs = torch.stack([pages[i] for i in group]).contiguous()
+                else:
+                    imgs = torch.from_numpy(np.stack([pages[i] for i in group])).to(self.dev, non_blocking=True)
                 out = torch.empty(rows // mm, c.hidden, dtype=torch.bfloat16, device=self.dev)
                 _lib.check(self.lib.hwocr_vit_forward(C.byref(self.vit), C.byref(ws), _lib.ptr(imgs), n, H, W, Pp,
                                                       _lib.ptr(self._pos_h), _lib.ptr(self._pos_w), _lib.ptr(self._seg),
@@ -414,7 +419,17 @@ class ReadEngine:
         if R > self.max_reads:
             raise ValueError(f"{R} reads exceed max_reads={self.max_reads}")
         st = _lib.stream_handle()
+        marks = []
+
+        def mark(name):
+            if self.collect_timings:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((name, ev))
+
+        mark("start")
         emb, grids, first = self.encode_pages(pages)
+        mark("vision")
         T = [len(p) for p in prompts]
         Tp = _ceil(max(T), 64)
         if Tp + max_new > self.ctx:
@@ -467,6 +482,7 @@ class ReadEngine:
             if return_logits:
                 first_logits.append(self._bufs["logits"][:n].clone())
             torch.cuda.current_stream().synchronize()  # the chunk's index tensors die with this iteration
+        mark("prefill")
         if return_logits:
             step_logits.append(torch.cat(first_logits, dim=0))
         if forced is not None:
@@ -499,7 +515,11 @@ class ReadEngine:
                     step_logits.append(self._bufs["logits"][:R].clone())
                 if forced is not None and i + 1 < max_new:
                     self.cur_ids[:R].copy_(torch.from_numpy(np.ascontiguousarray(forced[:, i + 1]).astype(np.int32)).to(dev))
+        mark("decode")
         torch.cuda.current_stream().synchronize()
+        if marks:
+            self.timings = {marks[i][0] + "_ms": marks[i - 1][1].elapsed_time(marks[i][1]) for i in range(1, len(marks))}
+            self.timings["decode_steps"] = max_new - 1
         toks = self.out_tokens[:R].cpu().numpy()
         ng = self.n_gen[:R].cpu().numpy()
         out = []

@@ -1,0 +1,61 @@
+"""One process per GPU: page sharding and the gather of token streams.
+
+The reference is strictly serial (one page, one read at a time: ocr_agent/transcribe.py:194-210, nodes.py:86-110).
+Reads are independent given the page, so a batch folder shards embarrassingly: the sorted page list
+(transcribe.py:185-187) is dealt round-robin to ranks, all reads of a page stay on one GPU, and the only collective
+is a gather of the generated token streams (<= 8 KB per read: latency-bound, any xGMI topology) to rank 0, which
+detokenises, merges and writes the per-page outputs.  Backend "nccl" is RCCL on ROCm; "gloo" serves CPU tests.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device_backend: bool = True) -> tuple[int, int, int]:
+    """(rank, local_rank, world).  Initialises torch.distributed when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        use_nccl = device_backend and torch.cuda.is_available()
+        if use_nccl:
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl" if use_nccl else "gloo", rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard(items: list, rank: int, world: int) -> list:
+    """Round-robin deal: rank r gets items r, r + world, ..."""
+    return items[rank::world]
+
+
+def owner_index(n_items: int, world: int) -> list[tuple[int, int]]:
+    """For every global item: (rank that reads it, its index within that rank's shard)."""
+    return [(i % world, i // world) for i in range(n_items)]
+
+
+def gather_token_streams(tokens: torch.Tensor, counts: torch.Tensor, dst: int = 0):
+    """tokens int32 [reads_local, N], counts int32 [reads_local] -> on `dst`: list over ranks of (tokens, counts)
+    trimmed to each rank's own read count; elsewhere None.  Ranks may hold different numbers of reads: everything is
+    padded to the maximum so that a single fixed-shape gather moves it."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [(tokens, counts)]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n_local = torch.tensor([tokens.shape[0]], dtype=torch.int32, device=tokens.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    n_max = int(max(int(s) for s in sizes))
+    width = tokens.shape[1]
+    buf = torch.zeros(n_max, width + 1, dtype=torch.int32, device=tokens.device)
+    buf[: tokens.shape[0], :width] = tokens
+    buf[: tokens.shape[0], width] = counts
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst)
+    if rank != dst:
+        return None
+    return [(out[r][: int(sizes[r]), :width], out[r][: int(sizes[r]), width]) for r in range(world)]

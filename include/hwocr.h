@@ -37,6 +37,8 @@ typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
 #define HWOCR_EPI_PARTIAL 5
 
 int hwocr_abi_version(void);
+/* text of the most recent launch failure in this process ("" if none): launcher name + HIP error */
+const char* hwocr_last_error(void);
 
 /* ---- single operators (each replaces the ATen op reached from the cited HF module) ------------------------- */
 
