@@ -48,12 +48,13 @@ class VitWs(C.Structure):
 
 
 class DecLayer(C.Structure):
-    _fields_ = [(n, P) for n in ("in_norm_w", "qkv_w", "qkv_b", "o_w", "post_norm_w", "gate_up_w", "down_w")]
+    _fields_ = [(n, P) for n in ("in_norm_w", "qkv_w", "qkv_b", "o_w", "post_norm_w", "gate_up_w", "down_w",
+                                  "qkv_wt", "o_wt", "gate_up_wt", "down_wt")]
 
 
 class Decoder(C.Structure):
     _fields_ = [(n, I) for n in ("layers", "hidden", "Hq", "Hkv", "inter", "vocab", "sec0", "sec1")] + [
-        ("eps", F), ("embed", P), ("lm_head", P), ("final_norm_w", P), ("L", C.POINTER(DecLayer)),
+        ("eps", F), ("embed", P), ("lm_head", P), ("lm_head_t", P), ("final_norm_w", P), ("L", C.POINTER(DecLayer)),
         ("rope_cos", P), ("rope_sin", P)]
 
 
@@ -74,7 +75,8 @@ _HIP_SIGS = {
     "hwocr_abi_version": ([], I),
     "hwocr_last_error": ([], C.c_char_p),
     "hwocr_gemm_wide": ([P, P, P, P, P, I, I, I, I, I, I, I, I, P], I),
-    "hwocr_gemm_skinny": ([P, P, P, P, I, I, I, I, I, I, I, I, P], I),
+    "hwocr_gemm_skinny": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P], I),
+    "hwocr_tile_weights": ([P, P, I, I, I, P], I),
     "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, P], I),
     "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, P], I),
     "hwocr_patchify": ([P, P, P, I, I, I, I, I, I, I, I, P], I),

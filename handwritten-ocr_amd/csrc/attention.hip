@@ -36,7 +36,7 @@ template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
   constexpr int HDP = (HD + 31) / 32 * 32;  // d rows of the V^T tile, padded to whole 32-row MFMA tiles
   constexpr int KS = HD * 2 + 16;           // K tile row stride (bytes): +1 slot -> conflict-free ds_read_b128
-  constexpr int VS = 136;                   // V^T tile row stride (bytes): 64 keys + 8 B -> conflict-free ds_read_b64
+  constexpr int VS = 144;                   // V^T tile row stride (bytes): 64 keys + 16 B -> conflict-free ds_read_b128
   constexpr int KBYTES = 64 * KS, VBYTES = HDP * VS;
   constexpr int NS = HD / 16, ND = HDP / 32;
   constexpr int CK = 64 * HD / 8, CV = HD * 8;             // 16-byte chunks per tile
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
   const bf16* Vp = a.VT + seg * a.v_seg + hk * a.v_head;
 
   const int qi = q0 + 32 * w + r;  // this lane's query column
+  const int rk = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);  // r with bits 2 and 3 swapped
   bf16x8 qf[NS];
   {
     const bf16* qrow = Qp + (long)min(qi, len - 1) * a.q_row + 8 * hh;
@@ -106,10 +107,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
       const int id = tid + 256 * i;
       if (id < CV) {
         const int d = id >> 3, ch = id & 7;
-        char* p = vb + d * VS + ch * 16;
-        const bf16x8 v = vreg[i];
-        *(bf16x4*)p = bf16x4{v[0], v[1], v[2], v[3]};
-        *(bf16x4*)(p + 8) = bf16x4{v[4], v[5], v[6], v[7]};
+        *(bf16x8*)(vb + d * VS + ch * 16) = vreg[i];
       }
     }
   };
@@ -130,48 +128,53 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
     const char* kb = smem + (t & 1) * (KBYTES + VBYTES);
     const char* vb = kb + KBYTES;
 
-    // ---- S^T = K . Q^T : rows = keys (registers), column = this lane's query
+    // ---- S^T = K . Q^T : rows = keys (registers), column = this lane's query.  MFMA tile row rho is fed key
+    // swap23(rho) (bits 2 and 3 exchanged), so register i of lane-half hh holds key 16(i>>3) + 8hh + (i&7):
+    // 8 consecutive keys per k-step, i.e. the natural B-operand order for the PV product below.
     f32x16 s0, s1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const bf16x8 k0 = *(const bf16x8*)(kb + r * KS + (16 * s + 8 * hh) * 2);
-      const bf16x8 k1 = *(const bf16x8*)(kb + (32 + r) * KS + (16 * s + 8 * hh) * 2);
+      const bf16x8 k0 = *(const bf16x8*)(kb + rk * KS + (16 * s + 8 * hh) * 2);
+      const bf16x8 k1 = *(const bf16x8*)(kb + (32 + rk) * KS + (16 * s + 8 * hh) * 2);
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
     }
     const bool need_mask = (j0 + 64 > len) || (CAUSAL && (j0 + 63 > q0 + 32 * w));
-    float mx = NEG_BIG;
+    if (need_mask) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      float v0 = s0[i] * a.scale_log2, v1 = s1[i] * a.scale_log2;
-      if (need_mask) {
-        const int key = j0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (key >= len || (CAUSAL && key > qi)) v0 = -INFINITY;
-        if (key + 32 >= len || (CAUSAL && key + 32 > qi)) v1 = -INFINITY;
+      for (int i = 0; i < 16; ++i) {
+        const int key = j0 + 16 * (i >> 3) + 8 * hh + (i & 7);
+        if (key >= len || (CAUSAL && key > qi)) s0[i] = -INFINITY;
+        if (key + 32 >= len || (CAUSAL && key + 32 > qi)) s1[i] = -INFINITY;
       }
-      s0[i] = v0; s1[i] = v1;
-      mx = fmaxf(mx, fmaxf(v0, v1));
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = exp2f(m - m_new);
+    float mx = NEG_BIG;  // raw (unscaled) scores; the positive scale commutes with max
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, fmaxf(s0[i], s1[i]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;
+    // running-max update only when some query of this wave saw a larger score (exact: alpha == 1 otherwise)
+    if (__any(mx > m)) {
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+      m = m_new;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      s0[i] = exp2f(s0[i] - m_new);
-      s1[i] = exp2f(s1[i] - m_new);
+      s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], a.scale_log2, -m));
+      s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], a.scale_log2, -m));
       rs += s0[i] + s1[i];
     }
-    l = l * alpha + rs;
-    m = m_new;
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    l += rs;
 
-    // ---- P^T as B operand: k-step (kt, s2) element j <-> key 32kt + 16s2 + 8(j>>2) + 4hh + (j&3)
+    // ---- P^T as B operand: k-step (kt, s2) element j <-> key 32kt + 16s2 + 8hh + j
     bf16x8 pb[2][2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
@@ -187,8 +190,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-          const char* p = vb + (d * 32 + r) * VS + (kt * 32 + 16 * s2 + 4 * hh) * 2;
-          const bf16x8 vf = cat4(*(const bf16x4*)p, *(const bf16x4*)(p + 16));
+          const bf16x8 vf = *(const bf16x8*)(vb + (d * 32 + r) * VS + (kt * 32 + 16 * s2 + 8 * hh) * 2);
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt][s2], o[d], 0, 0, 0);
         }
 
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
 template <int HD, bool CAUSAL>
 int launch_prefill(const PrefillArgs& a, int nseg, int heads, int max_len, hipStream_t st) {
   constexpr int HDP = (HD + 31) / 32 * 32;
-  constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HDP * 136);
+  constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HDP * 144);
   static bool done = false;
   if (!done) {
     hipFuncSetAttribute((const void*)attn_prefill_kernel<HD, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -242,7 +244,10 @@ struct DecodeArgs {
 
 constexpr int DEC_HD = 128;
 
-__global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs a) {
+// Keys are walked in blocks of 32.  MFMA tile rows are assigned to keys so that the score registers a lane ends up with
+// are 8 CONSECUTIVE keys (tile t, row 4a+r <-> key 8a + 4t + r): packed to bf16 they are the B operand of the PV product
+// in natural k order, and the matching A operand is one 16-byte load of a V^T row.
+__global__ __launch_bounds__(256, 3) void attn_decode_kernel(DecodeArgs a) {
   __shared__ float s_o[4][DEC_HD][16];
   __shared__ float s_m[4][16];
   __shared__ float s_l[4][16];
@@ -268,78 +273,64 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs a) {
   for (int d = 0; d < 8; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = NEG_BIG, l = 0.f;
 
-  const int nblk = (len + 63) >> 6;
+  const int krow = 8 * (c >> 2) + (c & 3);  // key (within the block) of tile-0 row c; tile 1: +4
+  const int nblk = (len + 31) >> 5;
   for (int kb = split * 4 + w; kb < nblk; kb += a.nsplit * 4) {
-    const int k0 = kb * 64;
-    bf16x8 kf[4][4];
-    bf16x4 vt[8][4];
+    const int k0 = kb * 32;
+    bf16x8 kf[2][4], vt[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bf16* krow = Kp + (long)min(k0 + 16 * t + c, len - 1) * DEC_HD + 8 * qd;
+    for (int t = 0; t < 2; ++t) {
+      const bf16* kr = Kp + (long)min(k0 + krow + 4 * t, len - 1) * DEC_HD + 8 * qd;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) kf[t][s] = *(const bf16x8*)(krow + 32 * s);
+      for (int s = 0; s < 4; ++s) kf[t][s] = *(const bf16x8*)(kr + 32 * s);
     }
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      const bf16* vrow = Vp + (long)(16 * d + c) * a.v_row + k0 + 4 * qd;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) vt[d][u] = *(const bf16x4*)(vrow + 16 * u);
-    }
-    if (k0 + 64 > len) {
+    for (int d = 0; d < 8; ++d) vt[d] = *(const bf16x8*)(Vp + (long)(16 * d + c) * a.v_row + k0 + 8 * qd);
+    if (k0 + 32 > len) {  // tail block: keys past the end carry p = 0, keep 0 * x finite
 #pragma unroll
       for (int d = 0; d < 8; ++d)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k0 + 16 * u + 4 * qd + e >= len) vt[d][u][e] = (bf16)0.0f;
+        for (int e = 0; e < 8; ++e)
+          if (k0 + 8 * qd + e >= len) vt[d][e] = (bf16)0.0f;
     }
-    // S^T tiles: rows = keys 16t + 4qd + r, column = query c
-    f32x4 sc[4];
+    // S^T tiles: lane (c, qd) register r of tile t <-> key k0 + 8qd + 4t + r, column = query c
+    f32x4 sc[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 2; ++t) {
       sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 4; ++s) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][s], qf[s], sc[t], 0, 0, 0);
     }
     float mx = NEG_BIG;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = sc[t][e] * a.scale_log2;
-        if (k0 + 16 * t + 4 * qd + e >= len) v = -INFINITY;
+        if (k0 + 8 * qd + 4 * t + e >= len) v = -INFINITY;
         sc[t][e] = v;
         mx = fmaxf(mx, v);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m, mx);
-    const float alpha = exp2f(m - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     float rs = 0.f;
+    bf16x8 pb;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        sc[t][e] = exp2f(sc[t][e] - m_new);
-        rs += sc[t][e];
+        const float pv = __builtin_amdgcn_exp2f(sc[t][e] - m_new);
+        rs += pv;
+        pb[4 * t + e] = f2bf(pv);
       }
     l = l * alpha + rs;
     m = m_new;
-    // P^T as B operand: k slot (qd, j): j<4 -> tile 2u key 4qd+j ; j>=4 -> tile 2u+1 key 4qd+j-4
-    bf16x8 pb[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        pb[u][e] = f2bf(sc[2 * u][e]);
-        pb[u][4 + e] = f2bf(sc[2 * u + 1][e]);
-      }
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
       o[d] *= alpha;
-      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat4(vt[d][0], vt[d][1]), pb[0], o[d], 0, 0, 0);
-      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat4(vt[d][2], vt[d][3]), pb[1], o[d], 0, 0, 0);
+      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[d], pb, o[d], 0, 0, 0);
     }
   }
   l += __shfl_xor(l, 16);
@@ -358,7 +349,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(DecodeArgs a) {
     float L = 0.f, O = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) {
-      const float f = exp2f(s_m[ww][qq] - M);
+      const float f = __builtin_amdgcn_exp2f(s_m[ww][qq] - M);
       L += s_l[ww][qq] * f;
       O += s_o[ww][d][qq] * f;
     }

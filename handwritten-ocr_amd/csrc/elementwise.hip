@@ -164,6 +164,73 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(RmsArgs a) {
   }
 }
 
+// Few rows (decode: one row per read): one 256-thread workgroup per row, every thread owns <= 1 chunk of 8 elements,
+// all slab loads of a thread are independent and in flight together; the row statistic goes through LDS.
+__global__ __launch_bounds__(256) void add_rmsnorm_row_kernel(RmsArgs a) {
+  __shared__ float s_part[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int row = blockIdx.x;
+  const int src = a.row_index ? a.row_index[row] : row;
+  const int nch = a.D >> 3;
+  const bool live = tid < nch;
+  float x[8];
+  float ss = 0.f;
+  if (live) {
+    const bf16x8 hv = *(const bf16x8*)(a.h + (long)src * a.ldh + tid * 8);
+    if (a.nslab > 0) {
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = 0.f;
+      const float* p = a.slabs + (long)src * a.ld_slab + tid * 8;
+      int s = 0;
+      for (; s + 4 <= a.nslab; s += 4) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v[2 * u] = *(const f32x4*)(p + (s + u) * a.slab_stride);
+          v[2 * u + 1] = *(const f32x4*)(p + (s + u) * a.slab_stride + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { y[e] += v[2 * u][e]; y[4 + e] += v[2 * u + 1][e]; }
+      }
+      for (; s < a.nslab; ++s) {
+        const f32x4 p0 = *(const f32x4*)(p + s * a.slab_stride), p1 = *(const f32x4*)(p + s * a.slab_stride + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y[e] += p0[e]; y[4 + e] += p1[e]; }
+      }
+      if (a.bias) {
+        const bf16x8 bb = *(const bf16x8*)(a.bias + tid * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] += bf2f(bb[e]);
+      }
+      bf16x8 hn;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { hn[e] = f2bf(rbf(y[e]) + bf2f(hv[e])); x[e] = bf2f(hn[e]); }
+      *(bf16x8*)(a.h + (long)src * a.ldh + tid * 8) = hn;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = bf2f(hv[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+  }
+  if (!a.out) return;
+  ss = wave_sum(ss);
+  if (lane == 0) s_part[w] = ss;
+  __syncthreads();
+  const float rstd = rsqrtf((s_part[0] + s_part[1] + s_part[2] + s_part[3]) / a.D + a.eps);
+  if (live) {
+    const bf16x8 g = *(const bf16x8*)(a.w + tid * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e] = a.gemma ? f2bf(x[e] * rstd * (1.0f + bf2f(g[e]))) : f2bf(bf2f(g[e]) * rbf(x[e] * rstd));
+    *(bf16x8*)(a.out + (long)row * a.ldo + tid * 8) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Vision rope + head split.  qkv[token][3][head][hd] -> Q,K [head][token][hd] (rotated, fp32 math then one
 // rounding: HF apply_rotary_pos_emb_vision modeling_qwen2_vl.py:239-248) and V^T [head][hd][token].
@@ -457,7 +524,10 @@ extern "C" int hwocr_add_rmsnorm(const float* slabs, int nslab, long slab_stride
   if (nslab > 0 && row_index) return HWOCR_EINVAL;
   RmsArgs a{slabs, nslab, slab_stride, ld_slab, (const bf16*)bias, (bf16*)h, ldh, (const bf16*)w, (bf16*)out, ldo,
             row_index, rows, D, eps, gemma};
-  hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  if (rows <= 512 && D <= 2048)
+    hipLaunchKernelGGL(add_rmsnorm_row_kernel, dim3(rows), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }
 

@@ -186,26 +186,54 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(WideArgs a) {
 // ------------------------------------------------------------------------------------------------
 // gemm_skinny
 // ------------------------------------------------------------------------------------------------
-constexpr int SK_KC = 256;    // K elements per LDS chunk of the activation slice
-
+// Work split: grid.x = tiles of (16*NT*WAVES) weight rows, grid.y = K slices.  Each wave streams its 16*NT weight rows
+// over the K slice in chunks of KC elements, one barrier per chunk.
 struct SkinnyArgs {
   const bf16* X; const bf16* W; const bf16* bias; void* out;
   int Bsz, N, K, ldx, ldw, ldo, kslice;
 };
 
-// NT = 16-row weight tiles per wave (2 -> 128 rows per workgroup, 1 -> 64: more workgroups for small N)
-template <int NB, int EPI, int NT>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NB*16][256] bf16, chunk p of row r holds p ^ (r&15)
+// TILED: W is stored in MFMA-fragment order [N/16][K/32][lane = 16*(k/8 % 4) + n % 16][8] (hwocr_tile_weights), so every
+// fragment load of a wave is one contiguous KiB and a wave streams one contiguous region; row-major W costs 16 rows x
+// 64 B per instruction, which the memory system serves at about half the rate (measured: LM head 141 -> 90 us).
+//
+// Pipeline: weights HBM -> VGPR (non-temporal 16-byte loads), activations L2 -> LDS by LDS-DMA, two stages: the loads
+// of chunk ci+1 are issued right after the barrier that publishes chunk ci and fly while chunk ci is multiplied.
+// (Tried and dropped, numbers in DESIGN.md: a third stage with asm-issued VGPR loads - the register allocator moved
+// the destinations before the data landed; everything through LDS-DMA - correct, but one workgroup per CU and the
+// DMA issue rate made it 1.5x slower.)
+template <int NB, int EPI, int NT, int WAVES, int KC, bool TILED>
+__global__ __launch_bounds__(64 * WAVES) void gemm_skinny_kernel(SkinnyArgs a) {
+  constexpr int KS = KC / 32;            // MFMA k-steps per chunk
+  constexpr int CPR = KC / 8;            // 16-byte chunks per activation row
+  constexpr int RPI = 64 / CPR;          // activation rows filled by one LDS-DMA instruction
+  constexpr int XBYTES = NB * 16 * KC * 2;
+  constexpr int NINST = NB * 16 / RPI / WAVES;  // LDS-DMA instructions per wave per chunk
+  static_assert((NB * 16 / RPI) % WAVES == 0, "activation staging must split evenly over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x [NB*16][KC] bf16; chunk p of row r holds p ^ (r & 15)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.x * (64 * NT) + 16 * NT * w;
+  const int n0 = blockIdx.x * (16 * NT * WAVES) + 16 * NT * w;
   const int ks = blockIdx.y;
   const int kbeg = ks * a.kslice, kend = min(a.K, kbeg + a.kslice);
+  const int nchunk = (kend - kbeg + KC - 1) / KC;
 
   const bf16* wrow[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) wrow[t] = a.W + (size_t)min(n0 + 16 * t + c, a.N - 1) * a.ldw + 8 * q;
+  for (int t = 0; t < NT; ++t) {
+    if constexpr (TILED)
+      wrow[t] = a.W + ((size_t)min((n0 >> 4) + t, (a.N >> 4) - 1) * (a.K >> 5) * 64 + lane) * 8;
+    else
+      wrow[t] = a.W + (size_t)min(n0 + 16 * t + c, a.N - 1) * a.ldw + 8 * q;
+  }
+  const bf16* xsrc[NINST];
+  int xlc[NINST];
+#pragma unroll
+  for (int i = 0; i < NINST; ++i) {
+    const int r = RPI * (w * NINST + i) + lane / CPR;
+    xlc[i] = ((lane % CPR) ^ (r & 15)) * 8;
+    xsrc[i] = a.X + (size_t)min(r, a.Bsz - 1) * a.ldx;
+  }
 
   f32x4 acc[NT][NB];
 #pragma unroll
@@ -213,45 +241,50 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kc = kbeg; kc < kend; kc += SK_KC) {
-    const int klen = min(SK_KC, kend - kc);  // multiple of 32
-    const int nks = klen >> 5;
-    // weights for this chunk: straight to VGPRs, all in flight before anything waits
-    bf16x8 wreg[NT][8];
+  bf16x8 wA[NT][KS], wB[NT][KS];
+  auto issue = [&](bf16x8 (&wr)[NT][KS], int ci) {
+    const int kc = kbeg + ci * KC;
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        wreg[t][s] = __builtin_nontemporal_load((const bf16x8*)(wrow[t] + min(kc + 32 * s, a.K - 32)));
-    __syncthreads();  // everyone finished reading the previous activation chunk
-    // activation chunk -> LDS by LDS-DMA: one instruction = 2 rows x 512 B
+      for (int t = 0; t < NT; ++t) {
+        const int kk = min(kc + 32 * s, a.K - 32);
+        wr[t][s] = __builtin_nontemporal_load((const bf16x8*)(wrow[t] + (TILED ? (size_t)(kk >> 5) * 512 : (size_t)kk)));
+      }
+    char* xb = smem + (ci & 1) * XBYTES + (w * NINST) * 1024;
 #pragma unroll
-    for (int i = 0; i < NB * 2; ++i) {
-      const int inst = w * (NB * 2) + i;
-      const int r = 2 * inst + (lane >> 5);
-      const int lc = (lane & 31) ^ (r & 15);
-      const int kk = min(kc + lc * 8, a.K - 8);
-      const bf16* src = a.X + (size_t)min(r, a.Bsz - 1) * a.ldx + kk;
-      __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR(smem + inst * 1024), 16, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    for (int i = 0; i < NINST; ++i)
+      __builtin_amdgcn_global_load_lds((const void*)(xsrc[i] + min(kc + xlc[i], a.K - 8)), LDS_PTR(xb + i * 1024), 16, 0, 0);
+  };
+  auto body = [&](int ci, bf16x8 (&cur)[NT][KS], bf16x8 (&nxt)[NT][KS]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // chunk ci (weights + activations), issued one iteration ago
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(cur[t][s]));  // plain register data from here on
+    __syncthreads();  // all waves: chunk ci visible, chunk ci-1 consumed -> the other buffer is free
+    if (ci + 1 < nchunk) issue(nxt, ci + 1);
+    const char* xb = smem + (ci & 1) * XBYTES;
+    const int nks = min(KS, (kend - (kbeg + ci * KC)) >> 5);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
       if (s < nks) {
-        bf16x8 xf[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const int r = 16 * b + c;
-          xf[b] = *(const bf16x8*)(smem + r * 512 + (((4 * s + q) ^ (r & 15)) << 4));
+          const bf16x8 xf = *(const bf16x8*)(xb + r * (KC * 2) + (((4 * s + q) ^ (r & 15)) << 4));
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[t][s], xf, acc[t][b], 0, 0, 0);
         }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int b = 0; b < NB; ++b)
-            acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[t][s], xf[b], acc[t][b], 0, 0, 0);
       }
     }
+  };
+
+  issue(wA, 0);
+  for (int ci = 0; ci < nchunk; ci += 2) {
+    body(ci, wA, wB);
+    if (ci + 1 < nchunk) body(ci + 1, wB, wA);
   }
 
   // lane (c,q): acc[t][b][r] = out[row 16b + c][n0 + 16t + 4q + r]
@@ -298,22 +331,43 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs a) {
   }
 }
 
+template <int NB, int EPI, int NT, int WAVES, int KC, bool TILED>
+void launch_skinny_one(const SkinnyArgs& a, int splitk, hipStream_t st) {
+  constexpr int LDS = 2 * NB * 16 * KC * 2;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<NB, EPI, NT, WAVES, KC, TILED>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    done = true;
+  }
+  const int rows = 16 * NT * WAVES;
+  dim3 grid((a.N + rows - 1) / rows, splitk), block(64 * WAVES);
+  hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI, NT, WAVES, KC, TILED>), grid, block, LDS, st, a);
+}
+template <int NB, int EPI, int NT, int WAVES, int KC>
+void launch_skinny_cfg(const SkinnyArgs& a, int splitk, bool tiled, hipStream_t st) {
+  if (tiled) launch_skinny_one<NB, EPI, NT, WAVES, KC, true>(a, splitk, st);
+  else launch_skinny_one<NB, EPI, NT, WAVES, KC, false>(a, splitk, st);
+}
+
+// KC: 256-element chunks while two activation buffers stay <= 64 KiB, else 128
 template <int NB>
-int launch_skinny(const SkinnyArgs& a, int epi, int splitk, hipStream_t st) {
-  // small N: 64-row workgroups so that the grid still covers the chip
-  const bool narrow = epi != EPI_SWIGLU && ((a.N + 127) / 128) * splitk < 256;
-  const int rows = narrow ? 64 : 128;
-  dim3 grid((a.N + rows - 1) / rows, splitk), block(256);
-  const size_t lds = (size_t)NB * 16 * 512;
+int launch_skinny(const SkinnyArgs& a, int epi, int splitk, bool tiled, hipStream_t st) {
+  constexpr int KC = NB <= 4 ? 256 : 128;
+  // few weight rows -> smaller workgroups so that the grid still covers the chip
+  const long wg4 = (long)((a.N + 127) / 128) * splitk;
   switch (epi) {
     case EPI_LINEAR:
-      if (narrow) hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI_LINEAR, 1>), grid, block, lds, st, a);
-      else hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI_LINEAR, 2>), grid, block, lds, st, a);
+      if (wg4 >= 512) launch_skinny_cfg<NB, EPI_LINEAR, 2, 4, KC>(a, splitk, tiled, st);
+      else launch_skinny_cfg<NB, EPI_LINEAR, 1, 2, KC>(a, splitk, tiled, st);
       break;
-    case EPI_SWIGLU: hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI_SWIGLU, 2>), grid, block, lds, st, a); break;
+    case EPI_SWIGLU:
+      if (wg4 >= 512) launch_skinny_cfg<NB, EPI_SWIGLU, 2, 4, KC>(a, splitk, tiled, st);
+      else launch_skinny_cfg<NB, EPI_SWIGLU, 2, 2, KC>(a, splitk, tiled, st);
+      break;
     case EPI_PARTIAL:
-      if (narrow) hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI_PARTIAL, 1>), grid, block, lds, st, a);
-      else hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI_PARTIAL, 2>), grid, block, lds, st, a);
+      if (wg4 >= 512) launch_skinny_cfg<NB, EPI_PARTIAL, 2, 4, KC>(a, splitk, tiled, st);
+      else launch_skinny_cfg<NB, EPI_PARTIAL, 1, 2, KC>(a, splitk, tiled, st);
       break;
     default: return HWOCR_EINVAL;
   }
@@ -399,8 +453,31 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
   return hwocr_launch_status();
 }
 
+// [N][K] row-major -> fragment-tiled copy for gemm_skinny (layout in the kernel comment).  16-byte granules.
+__global__ __launch_bounds__(256) void tile_weights_kernel(const bf16* src, bf16* dst, int N, int K, int ldw) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;  // one 16-byte granule each
+  const long total = (long)N * (K >> 3);
+  if (gid >= total) return;
+  const int lane = gid & 63;
+  const long blk = gid >> 6;  // (tile, kstep)
+  const int ksteps = K >> 5;
+  const int tile = blk / ksteps, kstep = blk % ksteps;
+  const int c = lane & 15, q = lane >> 4;
+  *(bf16x8*)(dst + gid * 8) = *(const bf16x8*)(src + (size_t)(tile * 16 + c) * ldw + kstep * 32 + q * 8);
+}
+
+extern "C" int hwocr_tile_weights(const void* src, void* dst, int N, int K, int ldw, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (N <= 0 || K <= 0 || (N % 16) || (K % 32) || (ldw % 8)) return HWOCR_EINVAL;
+  const long total = (long)N * (K >> 3);
+  hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     (const bf16*)src, (bf16*)dst, N, K, ldw);
+  return hwocr_launch_status();
+}
+
 extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out, int Bsz, int N,
-                                 int K, int ldx, int ldw, int ldo, int epi, int splitk, hipStream_t stream) {
+                                 int K, int ldx, int ldw, int ldo, int epi, int splitk, int w_tiled,
+                                 hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (Bsz <= 0 || Bsz > 128 || N <= 0 || K <= 0 || (K % 32) || (N % 16) || (epi == EPI_SWIGLU && (N % 32)) || (ldx % 8) || (ldw % 8) || (ldo % 4) ||
       splitk < 1)
@@ -408,17 +485,17 @@ extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias,
   if (epi != EPI_PARTIAL && splitk != 1) return HWOCR_EINVAL;
   if (epi == EPI_SWIGLU && bias) return HWOCR_EINVAL;
   // K slice per split: whole 256-element chunks
-  int chunks = (K + SK_KC - 1) / SK_KC;
+  int chunks = (K + 255) / 256;
   int per = (chunks + splitk - 1) / splitk;
-  SkinnyArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, out, Bsz, N, K, ldx, ldw, ldo, per * SK_KC};
+  SkinnyArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, out, Bsz, N, K, ldx, ldw, ldo, per * 256};
   if ((splitk - 1) * a.kslice >= K) return HWOCR_EINVAL;  // an empty slice would leave its slab unwritten
   const int nb = (Bsz + 15) / 16;
   switch (nb) {
-    case 1: return launch_skinny<1>(a, epi, splitk, stream);
-    case 2: return launch_skinny<2>(a, epi, splitk, stream);
-    case 3: return launch_skinny<3>(a, epi, splitk, stream);
-    case 4: return launch_skinny<4>(a, epi, splitk, stream);
-    case 5: case 6: return launch_skinny<6>(a, epi, splitk, stream);
-    default: return launch_skinny<8>(a, epi, splitk, stream);
+    case 1: return launch_skinny<1>(a, epi, splitk, w_tiled != 0, stream);
+    case 2: return launch_skinny<2>(a, epi, splitk, w_tiled != 0, stream);
+    case 3: return launch_skinny<3>(a, epi, splitk, w_tiled != 0, stream);
+    case 4: return launch_skinny<4>(a, epi, splitk, w_tiled != 0, stream);
+    case 5: case 6: return launch_skinny<6>(a, epi, splitk, w_tiled != 0, stream);
+    default: return launch_skinny<8>(a, epi, splitk, w_tiled != 0, stream);
   }
 }

@@ -22,7 +22,7 @@ inline bf16* B(void* p) { return (bf16*)p; }
 inline const bf16* B(const void* p) { return (const bf16*)p; }
 inline int pick_splitk(int K, int N, int want_wgs) {
   const int chunks = (K + 255) / 256;
-  const int tiles = (N + 63) / 64;
+  const int tiles = (N + 31) / 32;  // gemm_skinny's small-N configuration: 32 weight rows per workgroup
   int s = (want_wgs + tiles - 1) / tiles;
   if (s < 1) s = 1;
   if (s > chunks) s = chunks;
@@ -119,8 +119,8 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
   // final norm on the last prompt token of every read -> LM head -> first generated token
   CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->final_norm_w, ws->hn, Hd, last_rows, nseq, Hd,
                           m->eps, 0, st));
-  CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd, Hd, m->vocab,
-                          HWOCR_EPI_LINEAR, 1, st));
+  CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head_t ? m->lm_head_t : m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd,
+                          Hd, m->vocab, HWOCR_EPI_LINEAR, 1, m->lm_head_t != nullptr, st));
   CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids + seq0, gs->lens + seq0,
                              gs->n_gen + seq0, gs->finished + seq0, gs->out_tokens + (long)seq0 * gs->max_new,
                              gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, st));
@@ -134,7 +134,7 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   const int Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
   const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
   const float scale = 1.0f / sqrtf((float)HD);
-  const int s_qkv = pick_splitk(Hd, QW, 256), s_o = pick_splitk(OW, Hd, 256), s_d = pick_splitk(m->inter, Hd, 512);
+  const int s_qkv = pick_splitk(Hd, QW, 400), s_o = pick_splitk(OW, Hd, 400), s_d = pick_splitk(m->inter, Hd, 400);
   CHECK(hwocr_embed_splice(gs->cur_ids, nullptr, m->embed, nullptr, ws->h, nseq, Hd, 1.0f, st));
   CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->L[0].in_norm_w, ws->hn, Hd, nullptr, nseq, Hd,
                           m->eps, 0, st));
@@ -142,25 +142,27 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
     const hwocr_dec_layer& L = m->L[l];
     bf16* Kc = B(kv->k) + l * k_layer;
     bf16* Vc = B(kv->vt) + l * k_layer;
-    CHECK(hwocr_gemm_skinny(ws->hn, L.qkv_w, nullptr, ws->slabs, nseq, QW, Hd, Hd, Hd, QW, HWOCR_EPI_PARTIAL, s_qkv, st));
+    CHECK(hwocr_gemm_skinny(ws->hn, L.qkv_wt ? L.qkv_wt : L.qkv_w, nullptr, ws->slabs, nseq, QW, Hd, Hd, Hd, QW,
+                            HWOCR_EPI_PARTIAL, s_qkv, L.qkv_wt != nullptr, st));
     CHECK(hwocr_decode_qkv_finish(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, ws->q, Kc, Vc, gs->lens, gs->rope_delta,
                                   m->rope_cos, m->rope_sin, nseq, m->Hq, m->Hkv, k_seq, k_head, k_seq, k_head,
                                   kv->ctx, st));
     CHECK(hwocr_attn_decode(ws->q, Kc, Vc, gs->lens, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv,
                             attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, st));
-    CHECK(hwocr_gemm_skinny(ws->attn, L.o_w, nullptr, ws->slabs, nseq, Hd, OW, OW, OW, Hd, HWOCR_EPI_PARTIAL, s_o, st));
+    CHECK(hwocr_gemm_skinny(ws->attn, L.o_wt ? L.o_wt : L.o_w, nullptr, ws->slabs, nseq, Hd, OW, OW, OW, Hd,
+                            HWOCR_EPI_PARTIAL, s_o, L.o_wt != nullptr, st));
     CHECK(hwocr_add_rmsnorm(ws->slabs, s_o, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd,
                             nullptr, nseq, Hd, m->eps, 0, st));
-    CHECK(hwocr_gemm_skinny(ws->hn, L.gate_up_w, nullptr, ws->act, nseq, 2 * m->inter, Hd, Hd, Hd, m->inter,
-                            HWOCR_EPI_SWIGLU, 1, st));
-    CHECK(hwocr_gemm_skinny(ws->act, L.down_w, nullptr, ws->slabs, nseq, Hd, m->inter, m->inter, m->inter, Hd,
-                            HWOCR_EPI_PARTIAL, s_d, st));
+    CHECK(hwocr_gemm_skinny(ws->hn, L.gate_up_wt ? L.gate_up_wt : L.gate_up_w, nullptr, ws->act, nseq, 2 * m->inter, Hd,
+                            Hd, Hd, m->inter, HWOCR_EPI_SWIGLU, 1, L.gate_up_wt != nullptr, st));
+    CHECK(hwocr_gemm_skinny(ws->act, L.down_wt ? L.down_wt : L.down_w, nullptr, ws->slabs, nseq, Hd, m->inter, m->inter,
+                            m->inter, Hd, HWOCR_EPI_PARTIAL, s_d, L.down_wt != nullptr, st));
     const void* next_norm = (l + 1 < m->layers) ? m->L[l + 1].in_norm_w : m->final_norm_w;
     CHECK(hwocr_add_rmsnorm(ws->slabs, s_d, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, next_norm, ws->hn, Hd, nullptr,
                             nseq, Hd, m->eps, 0, st));
   }
-  CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd, Hd, m->vocab,
-                          HWOCR_EPI_LINEAR, 1, st));
+  CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head_t ? m->lm_head_t : m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd,
+                          Hd, m->vocab, HWOCR_EPI_LINEAR, 1, m->lm_head_t != nullptr, st));
   CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished,
                              gs->out_tokens, gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, st));
   return HWOCR_OK;

@@ -214,6 +214,7 @@ class ReadEngine:
         self.collect_timings = False
         self.timings = {}
         self._keep = []  # everything the C structs point at
+        self._tiled_keep = []
         self._graphs = {}
         self._bind_weights(normalize_keys(state_dict))
         self._alloc_state()
@@ -223,6 +224,14 @@ class ReadEngine:
         x = x.to(device=self.dev, dtype=torch.bfloat16).contiguous()
         self._keep.append(x)
         return x
+
+    def _tiled(self, w2d: torch.Tensor) -> torch.Tensor:
+        n, k = w2d.shape
+        out = torch.empty(n * k, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.hwocr_tile_weights(_lib.ptr(w2d), _lib.ptr(out), n, k, k, _lib.stream_handle()),
+                   "hwocr_tile_weights")
+        self._tiled_keep.append(out)
+        return out
 
     def _bind_weights(self, sd: dict) -> None:
         c = self.cfg
@@ -268,12 +277,16 @@ class ReadEngine:
             u = sd[p + "mlp.up_proj.weight"].reshape(c.inter // 16, 16, c.hidden)
             gu = torch.stack([g, u], dim=1).reshape(2 * c.inter, c.hidden)
             L = layers[l]
+            w_qkv, w_o = self._t(qkv_w), self._t(sd[p + "self_attn.o_proj.weight"])
+            w_gu, w_down = self._t(gu), self._t(sd[p + "mlp.down_proj.weight"])
             L.in_norm_w = P(self._t(sd[p + "input_layernorm.weight"]))
-            L.qkv_w, L.qkv_b = P(self._t(qkv_w)), P(self._t(qkv_b))
-            L.o_w = P(self._t(sd[p + "self_attn.o_proj.weight"]))
+            L.qkv_w, L.qkv_b = P(w_qkv), P(self._t(qkv_b))
+            L.o_w = P(w_o)
             L.post_norm_w = P(self._t(sd[p + "post_attention_layernorm.weight"]))
-            L.gate_up_w = P(self._t(gu))
-            L.down_w = P(self._t(sd[p + "mlp.down_proj.weight"]))
+            L.gate_up_w, L.down_w = P(w_gu), P(w_down)
+            # decode copies in MFMA-fragment order (contiguous KiB per fragment load; 288 GB of HBM pays for the copy)
+            L.qkv_wt, L.o_wt = P(self._tiled(w_qkv)), P(self._tiled(w_o))
+            L.gate_up_wt, L.down_wt = P(self._tiled(w_gu)), P(self._tiled(w_down))
         embed = self._t(sd[t + "embed_tokens.weight"])
         head = embed if (c.tie or "lm_head.weight" not in sd) else self._t(sd["lm_head.weight"])
         inv = 1.0 / (c.rope_theta ** (torch.arange(0, HD, 2, dtype=torch.float) / HD))
@@ -283,7 +296,7 @@ class ReadEngine:
         self.max_pos = ang.shape[0]
         self.dec = _lib.Decoder(layers=c.layers, hidden=c.hidden, Hq=c.q_heads, Hkv=c.kv_heads, inter=c.inter, vocab=c.vocab,
                                 sec0=c.mrope_section[0], sec1=c.mrope_section[0] + c.mrope_section[1], eps=c.eps,
-                                embed=P(embed), lm_head=P(head), final_norm_w=P(self._t(sd[t + "norm.weight"])), L=layers,
+                                embed=P(embed), lm_head=P(head), lm_head_t=P(self._tiled(head)), final_norm_w=P(self._t(sd[t + "norm.weight"])), L=layers,
                                 rope_cos=P(self.dec_cos), rope_sin=P(self.dec_sin))
         self._keep.append(layers)
         self.embed_weight = embed
@@ -487,7 +500,7 @@ class ReadEngine:
             step_logits.append(torch.cat(first_logits, dim=0))
         if forced is not None:
             self.cur_ids[:R].copy_(torch.from_numpy(np.ascontiguousarray(forced[:, 0]).astype(np.int32)).to(dev))
-        splits = self.attn_splits or max(1, min(16, 512 // max(1, R * c.kv_heads)))
+        splits = self.attn_splits or max(1, min(16, 768 // max(1, R * c.kv_heads)))
         steps = max_new - 1
         if use_graph and not return_logits and forced is None and steps > 0:
             key = (R, splits, max_new, min_new)

@@ -47,9 +47,14 @@ const char* hwocr_last_error(void);
 int hwocr_gemm_wide(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
                     int ldx, int ldw, int ldo, int ldres, int epi, hwocr_stream_t stream);
 
-/* Same contraction for <= 128 rows (decode).  epi PARTIAL writes fp32 slabs out[splitk][Bsz][ldo]. */
+/* Same contraction for <= 128 rows (decode).  epi PARTIAL writes fp32 slabs out[splitk][Bsz][ldo].
+ * w_tiled != 0: W is the fragment-tiled copy made by hwocr_tile_weights (ldw ignored). */
 int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out, int Bsz, int N, int K, int ldx,
-                      int ldw, int ldo, int epi, int splitk, hwocr_stream_t stream);
+                      int ldw, int ldo, int epi, int splitk, int w_tiled, hwocr_stream_t stream);
+
+/* [N][K] row-major weights -> [N/16][K/32][64 lanes][8] (lane = 16*((k/8)%4) + n%16): the order in which one wave's
+ * MFMA A fragments are consumed, so decode streams every weight byte as contiguous KiB blocks.  N%16 == 0, K%32 == 0. */
+int hwocr_tile_weights(const void* src, void* dst, int N, int K, int ldw, hwocr_stream_t stream);
 
 /* Whole-segment attention (HF modeling_qwen2_vl.py:375-418 vision, :553-569 decoder prefill).
  * Element strides; V is passed transposed (VT[d][key]); every segment's key range must be readable up to the
@@ -125,6 +130,7 @@ int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, const void* im
 
 typedef struct {
   const void *in_norm_w, *qkv_w, *qkv_b, *o_w, *post_norm_w, *gate_up_w, *down_w;
+  const void *qkv_wt, *o_wt, *gate_up_wt, *down_wt; /* fragment-tiled copies for decode (NULL: use the row-major ones) */
 } hwocr_dec_layer;
 
 typedef struct {
@@ -132,6 +138,7 @@ typedef struct {
   float eps;
   const void* embed;        /* [vocab][hidden] */
   const void* lm_head;      /* [vocab][hidden] (may alias embed) */
+  const void* lm_head_t;    /* fragment-tiled copy of lm_head for decode (may be NULL) */
   const void* final_norm_w;
   const hwocr_dec_layer* L; /* host array[layers] */
   const void *rope_cos, *rope_sin; /* bf16 [maxpos][64] */

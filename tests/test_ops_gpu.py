@@ -75,15 +75,32 @@ def test_gemm_wide_rejects_bad_shapes():
     assert lib().hwocr_gemm_wide(p(x), p(x), None, None, p(x), 64, 64, 72, 72, 72, 64, 0, 0, st()) == 1  # K % 64
 
 
+def _tiled(w):
+    n, k = w.shape
+    out = torch.empty(n * k, dtype=torch.bfloat16, device=DEV)
+    assert lib().hwocr_tile_weights(p(w), p(out), n, k, k, st()) == 0
+    return out
+
+
+def test_tile_weights_layout():
+    n, k = 48, 96
+    w = (torch.arange(n * k, dtype=torch.float32) % 251).view(n, k).to(torch.bfloat16).to(DEV)
+    t = _tiled(w).view(n // 16, k // 32, 4, 16, 8).cpu()
+    want = w.cpu().view(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4)
+    assert torch.equal(t, want)
+
+
+@pytest.mark.parametrize("tiled", [0, 1])
 @pytest.mark.parametrize("B", [1, 7, 16, 48, 96, 128])
 @pytest.mark.parametrize("N,K", [(96, 64), (2048, 1536), (1536, 2304)])
-def test_gemm_skinny_linear_and_partial(B, N, K):
+def test_gemm_skinny_linear_and_partial(B, N, K, tiled):
     x = randbf(B, K, seed=7)
     w = randbf(N, K, scale=K ** -0.5, seed=8)
+    wk = _tiled(w) if tiled else w
     bias = randbf(N, scale=0.5, seed=9)
     acc = x.float() @ w.float().t()
     out = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-    assert lib().hwocr_gemm_skinny(p(x), p(w), p(bias), p(out), B, N, K, K, K, N, 0, 1, st()) == 0
+    assert lib().hwocr_gemm_skinny(p(x), p(wk), p(bias), p(out), B, N, K, K, K, N, 0, 1, tiled, st()) == 0
     sync()
     assert_close_bf16(out, acc + bias.float(), ulps=2.0, atol=2e-3, what="skinny linear")
     chunks = (K + 255) // 256
@@ -92,19 +109,21 @@ def test_gemm_skinny_linear_and_partial(B, N, K):
         if (splitk - 1) * per * 256 >= K:
             continue
         slabs = torch.full((splitk, B, N), float("nan"), dtype=torch.float32, device=DEV)
-        assert lib().hwocr_gemm_skinny(p(x), p(w), None, p(slabs), B, N, K, K, K, N, 5, splitk, st()) == 0
+        assert lib().hwocr_gemm_skinny(p(x), p(wk), None, p(slabs), B, N, K, K, K, N, 5, splitk, tiled, st()) == 0
         sync()
         got = slabs.sum(0)
         assert torch.allclose(got, acc, rtol=1e-4, atol=2e-3), f"partial splitk={splitk}: {(got-acc).abs().max()}"
 
 
+@pytest.mark.parametrize("tiled", [0, 1])
 @pytest.mark.parametrize("B", [3, 48, 96])
-def test_gemm_skinny_swiglu(B):
+def test_gemm_skinny_swiglu(B, tiled):
     N, K = 2 * 1792, 1536
     x = randbf(B, K, seed=10)
     w = randbf(N, K, scale=K ** -0.5, seed=11)
+    wk = _tiled(w) if tiled else w
     out = torch.full((B, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
-    assert lib().hwocr_gemm_skinny(p(x), p(w), None, p(out), B, N, K, K, K, N // 2, 4, 1, st()) == 0
+    assert lib().hwocr_gemm_skinny(p(x), p(wk), None, p(out), B, N, K, K, K, N // 2, 4, 1, tiled, st()) == 0
     sync()
     assert_close_bf16(out, _swiglu_ref(x.float() @ w.float().t()), ulps=3.0, atol=2e-3, what="skinny swiglu")
 
@@ -211,7 +230,9 @@ def test_add_rmsnorm(rows, D, nslab):
         assert_close_bf16(h, x, ulps=1.0, atol=1e-3, what="residual write-back", mag=y.abs() + h_in.float().abs())
         x = h.float()
     want = w.float() * rbf(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
-    assert_close_bf16(out, want, ulps=1.5, atol=1e-3, what="rmsnorm")
+    # the row statistic is summed in a different order than torch's -> the normalised value may round to the neighbouring
+    # bf16 (1 ulp of it, up to 2 ulps of the product across a binade edge) before the weight multiply
+    assert_close_bf16(out, want, ulps=2.5, atol=1e-3, what="rmsnorm")
 
 
 def test_add_rmsnorm_gather():
