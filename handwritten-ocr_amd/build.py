@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-HIP_SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "runtime.hip"]
+HIP_SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "runtime.hip"]
 HIP_LIB = os.path.join(CSRC, "libhwocr_hip.so")
 TEXT_LIB = os.path.join(CSRC, "libhwocr_text.so")
 
@@ -41,13 +41,13 @@ def hipcc_path() -> str:
 
 def build_hip(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.cuh"), os.path.join(INCLUDE, "hwocr.h")]
+    deps = srcs + [os.path.join(CSRC, "gemm_common.cuh"), os.path.join(CSRC, "common.cuh"), os.path.join(INCLUDE, "hwocr.h")]
     if not force and _newer(HIP_LIB, deps):
         return HIP_LIB
     objs = []
     for s in srcs:
         o = s[:-4] + ".o"
-        if force or not _newer(o, [s, deps[-2], deps[-1]]):
+        if force or not _newer(o, [s] + deps[len(srcs):]):
             _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
                   "-I" + INCLUDE, "-c", s, "-o", o])
         objs.append(o)

@@ -16,30 +16,13 @@
 //
 // Epilogues reproduce the points where the reference's bf16 modules materialise a tensor
 // (HF modeling_qwen2_vl.py:293-301 VisionMlp, :453-466 Qwen2MLP, :442-448 residual adds).
-#include "common.cuh"
-#include "hwocr.h"
+#include "gemm_common.cuh"
+#include <cstdlib>
 #include <vector>
 
+using namespace gemm;
+
 namespace {
-
-enum : int {
-  EPI_LINEAR = HWOCR_EPI_LINEAR,        // bf16(acc + bias)
-  EPI_RESIDUAL = HWOCR_EPI_RESIDUAL,    // bf16(bf16(acc + bias) + res)
-  EPI_QUICKGELU = HWOCR_EPI_QUICKGELU,  // x*sigmoid(1.702x), each step rounded like the bf16 module chain
-  EPI_GELU = HWOCR_EPI_GELU,            // exact erf GELU of bf16(acc + bias)
-  EPI_SWIGLU = HWOCR_EPI_SWIGLU,        // rows interleaved [16 gate][16 up]: bf16(bf16(silu(g)) * u)
-  EPI_PARTIAL = HWOCR_EPI_PARTIAL       // fp32 split-K slab (skinny only)
-};
-
-__device__ __forceinline__ float act_quick_gelu(float v) {
-  const float t = rbf(1.702f * v);
-  const float s = rbf(1.0f / (1.0f + __expf(-t)));
-  return v * s;
-}
-__device__ __forceinline__ float act_gelu_erf(float v) {
-  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-}
-__device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }
 
 // ------------------------------------------------------------------------------------------------
 // gemm_wide
@@ -49,25 +32,14 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 constexpr int WIDE_LDS = 4 * TILE_BYTES; // 2 buffers x (X tile + W tile)
 constexpr int GROUP_M = 8;
 
-struct WideArgs {
-  const bf16* X; const bf16* W; const bf16* bias; const bf16* res; bf16* out;
-  int M, N, K, ldx, ldw, ldo, ldres, tilesM, tilesN;
-};
-
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(WideArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
 
-  // workgroup -> tile: XCD-contiguous chunks, then GROUP_M row panels swept column-major so that the
-  // workgroups resident on one XCD share a few X panels and W panels in its L2.
-  const int nwg = a.tilesM * a.tilesN;
-  const int wg = xcd_remap(blockIdx.x, nwg);
-  const int per_group = GROUP_M * a.tilesN;
-  const int g = wg / per_group, rem = wg - g * per_group;
-  const int gm = min(GROUP_M, a.tilesM - g * GROUP_M);
-  const int tm = g * GROUP_M + rem % gm, tn = rem / gm;
+  int tm, tn;
+  tile_of_block(a.tilesM, a.tilesN, GROUP_M, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- LDS-DMA staging plan: wave w fills rows 32w..32w+31 of both tiles, 8 rows (1 KiB) per instruction.
@@ -133,52 +105,12 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(WideArgs a) {
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = m0 + wm * 64 + mt * 16 + c;
-    if (m >= a.M) continue;
     if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-      for (int nt = 0; nt < 4; nt += 2) {
-        const int n = n0 + wn * 64 + nt * 16;  // gate rows n..n+15, up rows n+16..n+31
-        if (n >= a.N) continue;
-        const int j = (n >> 1) + 4 * q;
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float gte = rbf(acc[nt][mt][r]);
-          const float up = rbf(acc[nt + 1][mt][r]);
-          o[r] = f2bf(rbf(act_silu(gte)) * up);
-        }
-        *(bf16x4*)(a.out + (size_t)m * a.ldo + j) = o;
-      }
+      for (int nt = 0; nt < 4; nt += 2) store_swiglu(a, acc[nt][mt], acc[nt + 1][mt], m, n0 + wn * 64 + nt * 16, q);
     } else {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + 4 * q;
-        if (n >= a.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[nt][mt][r];
-        if (a.bias) {
-          const bf16x4 b = *(const bf16x4*)(a.bias + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += bf2f(b[r]);
-        }
-        bf16x4 o;
-        if constexpr (EPI == EPI_RESIDUAL) {
-          const bf16x4 rs = *(const bf16x4*)(a.res + (size_t)m * a.ldres + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(v[r]) + bf2f(rs[r]));
-        } else if constexpr (EPI == EPI_QUICKGELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = f2bf(act_quick_gelu(rbf(v[r])));
-        } else if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = f2bf(act_gelu_erf(rbf(v[r])));
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
-        }
-        *(bf16x4*)(a.out + (size_t)m * a.ldo + n) = o;
-      }
+      for (int nt = 0; nt < 4; ++nt) store_tile<EPI>(a, acc[nt][mt], m, n0 + wn * 64 + nt * 16 + 4 * q);
     }
   }
 }
@@ -425,6 +357,18 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
   if (epi == EPI_RESIDUAL && (!res || (ldres % 4))) return HWOCR_EINVAL;
   WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)out,
              M, N, K, ldx, ldw, ldo, ldres, (M + BM - 1) / BM, (N + BN - 1) / BN};
+  const bool prof = g_prof.on && g_prof.n < PROF_CAP;
+  static const bool use256 = [] { const char* e = getenv("HWOCR_GEMM256"); return !e || atoi(e) != 0; }();
+  if (use256 && M >= 1024 && N >= 256) {
+    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
+    const int rc = hwocr_gemm_wide256(a, epi, stream);
+    if (prof) {
+      (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], stream);
+      g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
+      ++g_prof.n;
+    }
+    return rc;
+  }
   dim3 grid(a.tilesM * a.tilesN), block(256);
   static bool attr_done = false;
   if (!attr_done) {
@@ -435,7 +379,6 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
     attr_done = true;
   }
-  const bool prof = g_prof.on && g_prof.n < PROF_CAP;
   if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
   switch (epi) {
     case EPI_LINEAR: hipLaunchKernelGGL(gemm_wide_kernel<EPI_LINEAR>, grid, block, WIDE_LDS, stream, a); break;

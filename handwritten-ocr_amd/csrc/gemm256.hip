@@ -1,0 +1,197 @@
+// 256x256x64 bf16 GEMM for the MFMA-bound part of a page read (vision tower, merger, decoder prefill).
+//
+// Why a second wide kernel: at 128x128 tiles every MFMA FLOP pulls twice the operand bytes L2 -> LDS; at full MFMA rate
+// that is 64 B/clk/CU, the whole L2->CU path.  A 256x256 tile halves it and one 512-thread workgroup owns the CU.
+//
+// Structure (one workgroup = 8 waves = 2(M) x 4(N), each wave a 128 x 64 output block = 8 x 4 MFMA 16x16x32 tiles):
+//   * LDS: 2 stages x (activation tile 256 x 64 + weight tile 256 x 64) bf16 = 128 KiB, rows of 128 B with the 16-byte
+//     chunks XOR-swizzled (conflict-free ds_read_b128), filled by LDS-DMA with the permutation on the SOURCE address.
+//   * A K tile is staged as 4 units of 16 KiB (2 DMA instructions per thread each), ordered as they are consumed:
+//       U0 = activation rows of both wave-rows' first 64-row half, U1 = weight rows of every wave-column's first
+//       32-row half, U2 = second weight halves, U3 = second activation halves.
+//   * A K tile is multiplied in 4 phases of 16 MFMAs per wave (one quadrant of the wave's block each):
+//       ph0 reads U0,U1 -> (m0,n0);  ph1 reads U2 -> (m0,n1);  ph2 reads U3 -> (m1,n1);  ph3 reads nothing -> (m1,n0).
+//   * Every phase issues ONE unit, 7 units (1.75 K tiles) ahead of the consumer; the unit it overwrites was last read one
+//     phase earlier.  Only ph3 waits, with a COUNTED vmcnt that retires the next K tile and leaves 3 units in flight.
+// The weight tile is the MFMA A operand, so each lane owns 4 consecutive output features (8-byte stores).
+#include "gemm_common.cuh"
+#include <type_traits>
+
+using namespace gemm;
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE = 256 * BK * 2;   // 32 KiB per operand tile
+constexpr int STAGE = 2 * TILE;      // activation tile, then weight tile
+constexpr int LDS_BYTES = 2 * STAGE; // 128 KiB
+constexpr int AHEAD = 7;             // units in flight ahead of the consuming phase
+
+template <int MH, int NH>
+__device__ __forceinline__ void quadrant_mma(f32x4 (&acc)[4][8], const bf16x8 (&wf)[2][2][2], const bf16x8 (&xf)[4][2]) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[2 * NH + j][4 * MH + i] =
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[NH][j][kk], xf[i][kk], acc[2 * NH + j][4 * MH + i], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+}
+
+__device__ __forceinline__ void wait_units_in_flight(int units) {  // 2 DMA instructions per unit per thread
+  switch (units) {
+    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int wr = w >> 2, wc = w & 3;
+  int tm, tn;
+  tile_of_block(a.tilesM, a.tilesN, 4, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging plan.  Unit kind k, instruction j: this thread copies one 16-byte chunk of tile row ubase[k] + r8 + 128 j
+  // (8 consecutive rows = 1 KiB per wave-instruction, lane-linear in LDS).
+  const int r8 = lane >> 3, p = lane & 7;
+  const int ubase[4] = {8 * w,                           // U0: activation rows 0..63 (+128)
+                        (w >> 2) * 64 + (w & 3) * 8,     // U1: weight rows {0..31, 64..95} (+128)
+                        (w >> 2) * 64 + (w & 3) * 8 + 32,  // U2: weight rows {32..63, 96..127} (+128)
+                        64 + 8 * w};                     // U3: activation rows 64..127 (+128)
+  const bf16* usrc[4][2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = ubase[k] + r8 + 128 * j;
+      const int lc = p ^ ((row >> 1) & 7);
+      usrc[k][j] = (k == 1 || k == 2) ? a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + lc * 8
+                                      : a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + lc * 8;
+    }
+  const int nk = a.K / BK;
+  auto issue = [&](auto kind, int t) {  // unit (t, kind): 2 LDS-DMA instructions per thread
+    constexpr int k = decltype(kind)::value;
+    if (t < nk) {
+      char* st = smem + (t & 1) * STAGE + ((k == 1 || k == 2) ? TILE : 0) + ubase[k] * 128;
+      __builtin_amdgcn_global_load_lds((const void*)(usrc[k][0] + t * BK), LDS_PTR(st), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)(usrc[k][1] + t * BK), LDS_PTR(st + 128 * 128), 16, 0, 0);
+    }
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+  const int total_units = 4 * nk;
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a stage: row*128 + ((chunk ^ ((row>>1)&7)) << 4), rows = 16-aligned base + c
+  const int sw = (c >> 1) & 7;
+  const int xrow0 = (128 * wr + c) * 128;          // + (64 mh + 16 i) * 128
+  const int wrow0 = TILE + (64 * wc + c) * 128;    // + (32 nh + 16 j) * 128
+  bf16x8 xf[4][2], wf[2][2][2];
+  auto read_x = [&](const char* st, int mh) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        xf[i][kk] = *(const bf16x8*)(st + xrow0 + (64 * mh + 16 * i) * 128 + (((kk * 4 + q) ^ sw) << 4));
+  };
+  auto read_w = [&](const char* st, int nh, bf16x8 (&dst)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        dst[j][kk] = *(const bf16x8*)(st + wrow0 + (32 * nh + 16 * j) * 128 + (((kk * 4 + q) ^ sw) << 4));
+  };
+  auto phase_end = [&]() {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: 7 units in flight, K tile 0 (units 0..3) landed
+  issue(K0{}, 0); issue(K1{}, 0); issue(K2{}, 0); issue(K3{}, 0);
+  issue(K0{}, 1); issue(K1{}, 1); issue(K2{}, 1);
+  wait_units_in_flight(max(0, min(3, total_units - 4)));
+  phase_end();
+
+  for (int t = 0; t < nk; ++t) {
+    const char* st = smem + (t & 1) * STAGE;
+    const int P = 4 * t;
+    // ph0: (m0, n0)
+    read_x(st, 0);
+    read_w(st, 0, wf[0]);
+    issue(K3{}, t + 1);  // unit P + 7
+    quadrant_mma<0, 0>(acc, wf, xf);
+    phase_end();
+    // ph1: (m0, n1)
+    read_w(st, 1, wf[1]);
+    issue(K0{}, t + 2);
+    quadrant_mma<0, 1>(acc, wf, xf);
+    phase_end();
+    // ph2: (m1, n1)
+    read_x(st, 1);
+    issue(K1{}, t + 2);
+    quadrant_mma<1, 1>(acc, wf, xf);
+    phase_end();
+    // ph3: (m1, n0); retire K tile t+1, keep the units issued behind it in flight
+    issue(K2{}, t + 2);
+    quadrant_mma<1, 0>(acc, wf, xf);
+    wait_units_in_flight(max(0, min(3, total_units - 1 - (P + 7))));
+    phase_end();
+  }
+
+  // ---- epilogue: lane (c,q) of tile (nt,mt) holds out[m0 + 128wr + 16mt + c][n0 + 64wc + 16nt + 4q .. +3]
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = m0 + 128 * wr + 16 * mt + c;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int nt = 0; nt < 4; nt += 2) store_swiglu(a, acc[nt][mt], acc[nt + 1][mt], m, n0 + 64 * wc + 16 * nt, q);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) store_tile<EPI>(a, acc[nt][mt], m, n0 + 64 * wc + 16 * nt + 4 * q);
+    }
+  }
+}
+
+template <int EPI>
+void launch(const WideArgs& a, hipStream_t st) {
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)gemm_wide256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    done = true;
+  }
+  WideArgs b = a;
+  b.tilesM = (a.M + BM - 1) / BM;
+  b.tilesN = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL(gemm_wide256_kernel<EPI>, dim3(b.tilesM * b.tilesN), dim3(512), LDS_BYTES, st, b);
+}
+
+}  // namespace
+
+int hwocr_gemm_wide256(const WideArgs& a, int epi, hipStream_t stream) {
+  switch (epi) {
+    case EPI_LINEAR: launch<EPI_LINEAR>(a, stream); break;
+    case EPI_RESIDUAL: launch<EPI_RESIDUAL>(a, stream); break;
+    case EPI_QUICKGELU: launch<EPI_QUICKGELU>(a, stream); break;
+    case EPI_GELU: launch<EPI_GELU>(a, stream); break;
+    case EPI_SWIGLU: launch<EPI_SWIGLU>(a, stream); break;
+    default: return HWOCR_EINVAL;
+  }
+  return hwocr_launch_status();
+}

@@ -1,0 +1,87 @@
+// Shared by the GEMM kernels: epilogue codes, activation helpers with the reference's bf16 rounding points, the
+// argument block of the wide kernels and the per-tile epilogue store.
+#pragma once
+#include "common.cuh"
+#include "hwocr.h"
+
+namespace gemm {
+
+enum : int {
+  EPI_LINEAR = HWOCR_EPI_LINEAR,        // bf16(acc + bias)
+  EPI_RESIDUAL = HWOCR_EPI_RESIDUAL,    // bf16(bf16(acc + bias) + res)
+  EPI_QUICKGELU = HWOCR_EPI_QUICKGELU,  // x*sigmoid(1.702x), each step rounded like the bf16 module chain
+  EPI_GELU = HWOCR_EPI_GELU,            // exact erf GELU of bf16(acc + bias)
+  EPI_SWIGLU = HWOCR_EPI_SWIGLU,        // rows interleaved [16 gate][16 up]: bf16(bf16(silu(g)) * u)
+  EPI_PARTIAL = HWOCR_EPI_PARTIAL       // fp32 split-K slab (skinny only)
+};
+
+__device__ __forceinline__ float act_quick_gelu(float v) {
+  const float t = rbf(1.702f * v);
+  const float s = rbf(1.0f / (1.0f + __expf(-t)));
+  return v * s;
+}
+__device__ __forceinline__ float act_gelu_erf(float v) {
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }
+
+struct WideArgs {
+  const bf16* X; const bf16* W; const bf16* bias; const bf16* res; bf16* out;
+  int M, N, K, ldx, ldw, ldo, ldres, tilesM, tilesN;
+};
+
+// One 16x16 MFMA tile whose A operand was the weight tile: the lane holds out[m][n .. n+3] (4 consecutive features).
+template <int EPI>
+__device__ __forceinline__ void store_tile(const WideArgs& a, const f32x4& acc, int m, int n) {
+  static_assert(EPI != EPI_SWIGLU, "SwiGLU consumes a (gate, up) tile pair: store_swiglu");
+  if (m >= a.M || n >= a.N) return;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = acc[r];
+  if (a.bias) {
+    const bf16x4 b = *(const bf16x4*)(a.bias + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += bf2f(b[r]);
+  }
+  bf16x4 o;
+  if constexpr (EPI == EPI_RESIDUAL) {
+    const bf16x4 rs = *(const bf16x4*)(a.res + (size_t)m * a.ldres + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(v[r]) + bf2f(rs[r]));
+  } else if constexpr (EPI == EPI_QUICKGELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(act_quick_gelu(rbf(v[r])));
+  } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(act_gelu_erf(rbf(v[r])));
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+  }
+  *(bf16x4*)(a.out + (size_t)m * a.ldo + n) = o;
+}
+
+// gate tile (weight rows n_gate .. +15) and the up tile that follows it -> out[m][n_gate/2 + 4q .. +3]
+__device__ __forceinline__ void store_swiglu(const WideArgs& a, const f32x4& g, const f32x4& u, int m, int n_gate, int q) {
+  if (m >= a.M || n_gate >= a.N) return;
+  bf16x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(act_silu(rbf(g[r]))) * rbf(u[r]));
+  *(bf16x4*)(a.out + (size_t)m * a.ldo + (n_gate >> 1) + 4 * q) = o;
+}
+
+// tile id of a workgroup: XCD-contiguous chunks, then GROUP row panels swept column-major (L2 reuse of both panels)
+__device__ __forceinline__ void tile_of_block(int tilesM, int tilesN, int group, int& tm, int& tn) {
+  const int nwg = tilesM * tilesN;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int per_group = group * tilesN;
+  const int g = wg / per_group, rem = wg - g * per_group;
+  const int gm = min(group, tilesM - g * group);
+  tm = g * group + rem % gm;
+  tn = rem / gm;
+}
+
+}  // namespace gemm
+
+// launcher of the 256x256 kernel (gemm256.hip); returns HWOCR_EINVAL when the shape does not qualify
+int hwocr_gemm_wide256(const gemm::WideArgs& a, int epi, hipStream_t stream);

@@ -40,7 +40,10 @@ def _swiglu_ref(acc):
     return (rbf(torch.nn.functional.silu(g)) * u).reshape(M, N // 2)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1000, 384, 1216), (257, 1536, 1536)])
+# shapes with M >= 1024 and N >= 256 run the 256x256 8-wave kernel (gemm256.hip), the others the 128x128 one
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1000, 384, 1216), (257, 1536, 1536),
+                                   (1024, 256, 64), (1300, 512, 128), (2048, 768, 1216), (1111, 1000, 192),
+                                   (5184, 1280, 320)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_wide(M, N, K, epi):
     x = randbf(M, K, scale=1.0, seed=1)
@@ -58,7 +61,7 @@ def test_gemm_wide(M, N, K, epi):
     assert_close_bf16(out, want, ulps=2.0, atol=2e-3, what=f"gemm_wide epi={epi}", mag=mag)
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (129, 17920 // 10, 1536)])
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (129, 17920 // 10, 1536), (1328, 1792, 1536), (2100, 608, 192)])
 def test_gemm_wide_swiglu(M, N, K):
     N = (N // 32) * 32
     x = randbf(M, K, seed=5)
