@@ -59,7 +59,7 @@ class Decoder(C.Structure):
 
 
 class Kv(C.Structure):
-    _fields_ = [("k", P), ("vt", P), ("nseq_max", I), ("ctx", I)]
+    _fields_ = [("k", P), ("vt", P), ("nseq_max", I), ("ctx", I), ("tiled", I)]
 
 
 class DecWs(C.Structure):
@@ -77,14 +77,14 @@ _HIP_SIGS = {
     "hwocr_gemm_wide": ([P, P, P, P, P, I, I, I, I, I, I, I, I, P], I),
     "hwocr_gemm_skinny": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "hwocr_tile_weights": ([P, P, I, I, I, P], I),
-    "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, P], I),
-    "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, P], I),
+    "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, I, P], I),
+    "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, P], I),
     "hwocr_patchify": ([P, P, P, I, I, I, I, I, I, I, I, P], I),
     "hwocr_layernorm": ([P, P, P, P, I, I, I, I, F, P], I),
     "hwocr_add_rmsnorm": ([P, I, L, I, P, P, I, P, P, I, P, I, I, F, I, P], I),
     "hwocr_vit_rope_split": ([P, P, P, P, P, P, P, P, I, I, I, I, P], I),
-    "hwocr_mrope_kv_prefill": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, P], I),
-    "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, P], I),
+    "hwocr_mrope_kv_prefill": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, I, P], I),
+    "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, I, P], I),
     "hwocr_embed_splice": ([P, P, P, P, P, I, I, F, P], I),
     "hwocr_argmax_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P], I),
     "hwocr_vit_forward": ([C.POINTER(Vit), C.POINTER(VitWs), P, I, I, I, I, P, P, P, P, P], I),

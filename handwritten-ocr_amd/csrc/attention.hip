@@ -26,6 +26,7 @@ struct PrefillArgs {
   long o_seg, o_row;
   int group;          // query heads per kv head
   float scale_log2;   // softmax scale * log2(e)
+  int kv_tiled;       // K / V^T in the fragment-tiled cache layout (common.cuh) instead of rows
 };
 
 __device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
       const int id = tid + 256 * i;
       if (id < CK) {
         const int row = id / (HD / 8), ch = id % (HD / 8);
-        kreg[i] = *(const bf16x8*)(Kp + (long)min(j0 + row, len - 1) * a.k_row + ch * 8);
+        const int key = min(j0 + row, len - 1);
+        kreg[i] = *(const bf16x8*)(Kp + (a.kv_tiled ? kv_tiled_k(key, ch * 8) : (long)key * a.k_row + ch * 8));
       }
     }
 #pragma unroll
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
       const int id = tid + 256 * i;
       if (id < CV) {
         const int d = id >> 3, ch = id & 7;
-        bf16x8 v = *(const bf16x8*)(Vp + (long)d * a.v_row + j0 + ch * 8);
+        bf16x8 v = *(const bf16x8*)(Vp + (a.kv_tiled ? kv_tiled_v(d, j0 + ch * 8) : (long)d * a.v_row + j0 + ch * 8));
         if (j0 + 64 > len) {  // tail tile: keys past the segment carry p = 0, keep 0 * x finite
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -240,6 +242,7 @@ struct DecodeArgs {
   long k_seq, k_head, v_seq, v_head, v_row;
   int Hq, Hkv, G, nsplit;
   float scale_log2;
+  int kv_tiled;
 };
 
 constexpr int DEC_HD = 128;
@@ -247,6 +250,7 @@ constexpr int DEC_HD = 128;
 // Keys are walked in blocks of 32.  MFMA tile rows are assigned to keys so that the score registers a lane ends up with
 // are 8 CONSECUTIVE keys (tile t, row 4a+r <-> key 8a + 4t + r): packed to bf16 they are the B operand of the PV product
 // in natural k order, and the matching A operand is one 16-byte load of a V^T row.
+template <bool TILED>
 __global__ __launch_bounds__(256, 3) void attn_decode_kernel(DecodeArgs a) {
   __shared__ float s_o[4][DEC_HD][16];
   __shared__ float s_m[4][16];
@@ -278,14 +282,25 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(DecodeArgs a) {
   for (int kb = split * 4 + w; kb < nblk; kb += a.nsplit * 4) {
     const int k0 = kb * 32;
     bf16x8 kf[2][4], vt[8];
+    if constexpr (TILED) {  // one contiguous KiB per fragment, the cache is stored in operand order
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const bf16* kr = Kp + (long)min(k0 + krow + 4 * t, len - 1) * DEC_HD + 8 * qd;
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) kf[t][s] = *(const bf16x8*)(kr + 32 * s);
+        for (int s = 0; s < 4; ++s)
+          kf[t][s] = __builtin_nontemporal_load((const bf16x8*)(Kp + ((((long)kb * 2 + t) * 4 + s) * 64 + lane) * 8));
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        vt[d] = __builtin_nontemporal_load((const bf16x8*)(Vp + (((long)kb * 8 + d) * 64 + lane) * 8));
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16* kr = Kp + (long)min(k0 + krow + 4 * t, len - 1) * DEC_HD + 8 * qd;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[t][s] = *(const bf16x8*)(kr + 32 * s);
+      }
+#pragma unroll
+      for (int d = 0; d < 8; ++d) vt[d] = *(const bf16x8*)(Vp + (long)(16 * d + c) * a.v_row + k0 + 8 * qd);
     }
-#pragma unroll
-    for (int d = 0; d < 8; ++d) vt[d] = *(const bf16x8*)(Vp + (long)(16 * d + c) * a.v_row + k0 + 8 * qd);
     if (k0 + 32 > len) {  // tail block: keys past the end carry p = 0, keep 0 * x finite
 #pragma unroll
       for (int d = 0; d < 8; ++d)
@@ -387,7 +402,7 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
                                   int nseg, int heads, int group, int head_dim, int max_len, int causal,
                                   long q_seg, long q_head, long q_row, long k_seg, long k_head, long k_row,
                                   long v_seg, long v_head, long v_row, long o_seg, long o_row, float scale,
-                                  hipStream_t stream) {
+                                  int kv_tiled, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseg <= 0 || heads <= 0 || group <= 0 || max_len <= 0) return HWOCR_EINVAL;
   if ((q_row % 8) || (k_row % 8) || (v_row % 8) || (o_row % 4) || (q_head % 8) || (k_head % 8) || (v_head % 8) ||
@@ -395,7 +410,8 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
     return HWOCR_EINVAL;
   PrefillArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, (bf16*)O, lens,
                 q_seg, q_head, q_row, k_seg, k_head, k_row, v_seg, v_head, v_row, o_seg, o_row,
-                group, scale * 1.4426950408889634f};
+                group, scale * 1.4426950408889634f, kv_tiled};
+  if (kv_tiled && head_dim != 128) return HWOCR_EINVAL;
   if (head_dim == 80) return causal ? launch_prefill<80, true>(a, nseg, heads, max_len, stream)
                                     : launch_prefill<80, false>(a, nseg, heads, max_len, stream);
   if (head_dim == 128) return causal ? launch_prefill<128, true>(a, nseg, heads, max_len, stream)
@@ -410,14 +426,15 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
 extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out,
                                  float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit,
                                  long k_seq, long k_head, long v_seq, long v_head, long v_row, float scale,
-                                 hipStream_t stream) {
+                                 int kv_tiled, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseq <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16 || nsplit < 1) return HWOCR_EINVAL;
   if (nsplit > 1 && (!part_o || !part_ml)) return HWOCR_EINVAL;
   if ((v_row % 64) || (k_seq % 8) || (k_head % 8) || (v_seq % 8) || (v_head % 8)) return HWOCR_EINVAL;
   DecodeArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, lens, part_o, part_ml, (bf16*)out,
-               k_seq, k_head, v_seq, v_head, v_row, Hq, Hkv, Hq / Hkv, nsplit, scale * 1.4426950408889634f};
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+               k_seq, k_head, v_seq, v_head, v_row, Hq, Hkv, Hq / Hkv, nsplit, scale * 1.4426950408889634f, kv_tiled};
+  if (kv_tiled) hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
   if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(Hkv, nseq), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }

@@ -49,6 +49,19 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
+// Fragment-tiled KV-cache layout (decode streams the cache as contiguous KiB blocks, exactly in MFMA operand order).
+// Offsets are in elements inside one (read, kv head) region of ctx*128 elements; keys come in blocks of 32.
+//   K : [block][tile t=0,1][d-step s=0..3][lane = 16*((d%32)/8) + c][8]   with tile row c <-> key 8(c>>2) + (c&3) + 4t
+//   V^T: [block][d-tile 0..7][lane = 16*((key%32)/8) + d%16][8 keys]
+__device__ __forceinline__ long kv_tiled_k(int key, int d) {
+  const int kl = key & 31, t = (kl >> 2) & 1, c = ((kl >> 3) << 2) | (kl & 3);
+  return (((((long)(key >> 5) * 2 + t) * 4 + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + c) << 3) + (d & 7);
+}
+__device__ __forceinline__ long kv_tiled_v(int d, int key) {
+  const int kl = key & 31;
+  return ((((long)(key >> 5) * 8 + (d >> 4)) * 64 + (kl >> 3) * 16 + (d & 15)) << 3) + (kl & 7);
+}
+
 // last launch failure of this process (which launcher, which HIP error): read back through hwocr_last_error()
 extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text);
 static inline int hwocr_launch_status_at(const char* where) {

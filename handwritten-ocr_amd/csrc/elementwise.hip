@@ -306,6 +306,7 @@ struct MropeArgs {
   const bf16* cos_tab; const bf16* sin_tab;                  // [maxpos][64]
   int rows, rows_per_seq, Hq, Hkv, sec0, sec1;
   long k_seq, k_head, v_seq, v_head, v_row;
+  int tiled;
 };
 constexpr int DHD = 128;
 
@@ -338,10 +339,15 @@ __global__ __launch_bounds__(256) void mrope_kv_prefill_kernel(MropeArgs a) {
       mrope_pair(*(const bf16x8*)src, *(const bf16x8*)(src + 64), 8 * j, a.pos[row], a.pos[a.rows + row],
                  a.pos[2 * a.rows + row], a, oa, ob);
       const int sq = row / a.rows_per_seq, slot = row % a.rows_per_seq;
-      bf16* dst = isk ? a.K + sq * a.k_seq + (hy - a.Hq) * a.k_head + (long)slot * DHD + 8 * j
-                      : a.Q + (long)row * a.Hq * DHD + hy * DHD + 8 * j;
-      *(bf16x8*)dst = oa;
-      *(bf16x8*)(dst + 64) = ob;
+      if (isk) {
+        bf16* kb = a.K + sq * a.k_seq + (hy - a.Hq) * a.k_head;
+        *(bf16x8*)(kb + (a.tiled ? kv_tiled_k(slot, 8 * j) : (long)slot * DHD + 8 * j)) = oa;
+        *(bf16x8*)(kb + (a.tiled ? kv_tiled_k(slot, 64 + 8 * j) : (long)slot * DHD + 64 + 8 * j)) = ob;
+      } else {
+        bf16* dst = a.Q + (long)row * a.Hq * DHD + hy * DHD + 8 * j;
+        *(bf16x8*)dst = oa;
+        *(bf16x8*)(dst + 64) = ob;
+      }
     }
   } else {
     const int hk = hy - a.Hq - a.Hkv;
@@ -358,8 +364,10 @@ __global__ __launch_bounds__(256) void mrope_kv_prefill_kernel(MropeArgs a) {
     const int rr = tid & 63, dg = tid >> 6;
     const int row = r0 + rr;
     if (row < a.rows) {
-      bf16* dst = a.VT + (row / a.rows_per_seq) * a.v_seq + hk * a.v_head + row % a.rows_per_seq;
-      for (int d = dg * 32; d < dg * 32 + 32; ++d) dst[(long)d * a.v_row] = s_v[rr][d];
+      const int slot = row % a.rows_per_seq;
+      bf16* vb = a.VT + (row / a.rows_per_seq) * a.v_seq + hk * a.v_head;
+      for (int d = dg * 32; d < dg * 32 + 32; ++d)
+        vb[a.tiled ? kv_tiled_v(d, slot) : (long)d * a.v_row + slot] = s_v[rr][d];
     }
   }
 }
@@ -370,7 +378,7 @@ struct DecQkvArgs {
   const bf16* bias; bf16* Q; bf16* K; bf16* VT;
   const int* lens; const int* rope_delta;
   const bf16* cos_tab; const bf16* sin_tab;
-  int Hq, Hkv; long k_seq, k_head, v_seq, v_head, v_row;
+  int Hq, Hkv; long k_seq, k_head, v_seq, v_head, v_row; int tiled;
 };
 __global__ __launch_bounds__(256) void decode_qkv_finish_kernel(DecQkvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -405,14 +413,20 @@ __global__ __launch_bounds__(256) void decode_qkv_finish_kernel(DecQkvArgs a) {
     const float x1 = bf2f(row[hy * DHD + i]), x2 = bf2f(row[hy * DHD + 64 + i]);
     const bf16 oa = f2bf(rbf(x1 * cs) + rbf(-x2 * sn));
     const bf16 ob = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
-    bf16* dst = hy < a.Hq ? a.Q + ((long)b * a.Hq + hy) * DHD
-                          : a.K + b * a.k_seq + (hy - a.Hq) * a.k_head + (long)slot * DHD;
-    dst[i] = oa;
-    dst[64 + i] = ob;
+    if (hy < a.Hq) {
+      bf16* dst = a.Q + ((long)b * a.Hq + hy) * DHD;
+      dst[i] = oa;
+      dst[64 + i] = ob;
+    } else {
+      bf16* kb = a.K + b * a.k_seq + (hy - a.Hq) * a.k_head;
+      kb[a.tiled ? kv_tiled_k(slot, i) : (long)slot * DHD + i] = oa;
+      kb[a.tiled ? kv_tiled_k(slot, 64 + i) : (long)slot * DHD + 64 + i] = ob;
+    }
   }
   for (int id = tid; id < a.Hkv * DHD; id += 256) {
     const int hk = id / DHD, d = id % DHD;
-    a.VT[b * a.v_seq + hk * a.v_head + (long)d * a.v_row + slot] = row[(a.Hq + a.Hkv) * DHD + id];
+    a.VT[b * a.v_seq + hk * a.v_head + (a.tiled ? kv_tiled_v(d, slot) : (long)d * a.v_row + slot)] =
+        row[(a.Hq + a.Hkv) * DHD + id];
   }
 }
 
@@ -545,11 +559,12 @@ extern "C" int hwocr_vit_rope_split(const void* qkv, void* Q, void* K, void* VT,
 extern "C" int hwocr_mrope_kv_prefill(const void* qkv, void* Q, void* K, void* VT, const int* pos,
                                       const void* cos_tab, const void* sin_tab, int rows, int rows_per_seq, int Hq,
                                       int Hkv, int sec0, int sec1, long k_seq, long k_head, long v_seq, long v_head,
-                                      long v_row, hipStream_t stream) {
+                                      long v_row, int kv_tiled, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (rows <= 0 || Hq <= 0 || Hkv <= 0 || rows_per_seq <= 0 || rows_per_seq > v_row) return HWOCR_EINVAL;
   MropeArgs a{(const bf16*)qkv, (bf16*)Q, (bf16*)K, (bf16*)VT, pos, (const bf16*)cos_tab,
-              (const bf16*)sin_tab, rows, rows_per_seq, Hq, Hkv, sec0, sec1, k_seq, k_head, v_seq, v_head, v_row};
+              (const bf16*)sin_tab, rows, rows_per_seq, Hq, Hkv, sec0, sec1, k_seq, k_head, v_seq, v_head, v_row,
+              kv_tiled};
   hipLaunchKernelGGL(mrope_kv_prefill_kernel, dim3((rows + 63) / 64, Hq + 2 * Hkv), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }
@@ -557,12 +572,12 @@ extern "C" int hwocr_mrope_kv_prefill(const void* qkv, void* Q, void* K, void* V
 extern "C" int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_stride, const void* bias, void* Q,
                                        void* K, void* VT, const int* lens, const int* rope_delta,
                                        const void* cos_tab, const void* sin_tab, int nseq, int Hq, int Hkv,
-                                       long k_seq, long k_head, long v_seq, long v_head, long v_row,
+                                       long k_seq, long k_head, long v_seq, long v_head, long v_row, int kv_tiled,
                                        hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseq <= 0 || nslab < 1 || !slabs) return HWOCR_EINVAL;
   DecQkvArgs a{slabs, nslab, slab_stride, (const bf16*)bias, (bf16*)Q, (bf16*)K, (bf16*)VT, lens, rope_delta,
-               (const bf16*)cos_tab, (const bf16*)sin_tab, Hq, Hkv, k_seq, k_head, v_seq, v_head, v_row};
+               (const bf16*)cos_tab, (const bf16*)sin_tab, Hq, Hkv, k_seq, k_head, v_seq, v_head, v_row, kv_tiled};
   hipLaunchKernelGGL(decode_qkv_finish_kernel, dim3(nseq), dim3(256), (size_t)(Hq + 2 * Hkv) * DHD * 2, stream, a);
   return hwocr_launch_status();
 }

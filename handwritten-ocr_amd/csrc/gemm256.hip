@@ -15,6 +15,7 @@
 //     phase earlier.  Only ph3 waits, with a COUNTED vmcnt that retires the next K tile and leaves 3 units in flight.
 // The weight tile is the MFMA A operand, so each lane owns 4 consecutive output features (8-byte stores).
 #include "gemm_common.cuh"
+#include <cstdlib>
 #include <type_traits>
 
 using namespace gemm;
@@ -50,7 +51,12 @@ __device__ __forceinline__ void wait_units_in_flight(int units) {  // 2 DMA inst
   }
 }
 
-template <int EPI>
+// STAGGER: the two wave-rows run half a phase apart (load segment | multiply segment, a barrier between segments): while
+// waves 0-3 multiply, waves 4-7 fetch their fragments and vice versa, so the matrix pipe of every SIMD always has one of
+// its two waves ready.  Costs a second barrier per phase; LDS hazards hold because every unit is overwritten 7 phases
+// (14 segments) after... see the window derivation in DESIGN.md: last read of the old occupant at segment 2P-15, first
+// DMA of the new one at 2P-14; the retiring wait of the late half moves from after its multiply to after its load segment.
+template <int EPI, bool STAGGER>
 __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -129,30 +135,62 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   wait_units_in_flight(max(0, min(3, total_units - 4)));
   phase_end();
 
-  for (int t = 0; t < nk; ++t) {
-    const char* st = smem + (t & 1) * STAGE;
-    const int P = 4 * t;
-    // ph0: (m0, n0)
-    read_x(st, 0);
-    read_w(st, 0, wf[0]);
-    issue(K3{}, t + 1);  // unit P + 7
-    quadrant_mma<0, 0>(acc, wf, xf);
-    phase_end();
-    // ph1: (m0, n1)
-    read_w(st, 1, wf[1]);
-    issue(K0{}, t + 2);
-    quadrant_mma<0, 1>(acc, wf, xf);
-    phase_end();
-    // ph2: (m1, n1)
-    read_x(st, 1);
-    issue(K1{}, t + 2);
-    quadrant_mma<1, 1>(acc, wf, xf);
-    phase_end();
-    // ph3: (m1, n0); retire K tile t+1, keep the units issued behind it in flight
-    issue(K2{}, t + 2);
-    quadrant_mma<1, 0>(acc, wf, xf);
-    wait_units_in_flight(max(0, min(3, total_units - 1 - (P + 7))));
-    phase_end();
+  if constexpr (!STAGGER) {
+    for (int t = 0; t < nk; ++t) {
+      const char* st = smem + (t & 1) * STAGE;
+      const int P = 4 * t;
+      // ph0: (m0, n0)
+      read_x(st, 0);
+      read_w(st, 0, wf[0]);
+      issue(K3{}, t + 1);  // unit P + 7
+      quadrant_mma<0, 0>(acc, wf, xf);
+      phase_end();
+      // ph1: (m0, n1)
+      read_w(st, 1, wf[1]);
+      issue(K0{}, t + 2);
+      quadrant_mma<0, 1>(acc, wf, xf);
+      phase_end();
+      // ph2: (m1, n1)
+      read_x(st, 1);
+      issue(K1{}, t + 2);
+      quadrant_mma<1, 1>(acc, wf, xf);
+      phase_end();
+      // ph3: (m1, n0); retire K tile t+1, keep the units issued behind it in flight
+      issue(K2{}, t + 2);
+      quadrant_mma<1, 0>(acc, wf, xf);
+      wait_units_in_flight(max(0, min(3, total_units - 1 - (P + 7))));
+      phase_end();
+    }
+  } else {
+    const bool late = wr == 1;  // wave-uniform
+    if (late) phase_end();
+    for (int t = 0; t < nk; ++t) {
+      const char* st = smem + (t & 1) * STAGE;
+      const int keep = max(0, min(3, total_units - 1 - (4 * t + 7)));
+      read_x(st, 0);
+      read_w(st, 0, wf[0]);
+      issue(K3{}, t + 1);
+      phase_end();
+      quadrant_mma<0, 0>(acc, wf, xf);
+      phase_end();
+      read_w(st, 1, wf[1]);
+      issue(K0{}, t + 2);
+      phase_end();
+      quadrant_mma<0, 1>(acc, wf, xf);
+      phase_end();
+      read_x(st, 1);
+      issue(K1{}, t + 2);
+      phase_end();
+      quadrant_mma<1, 1>(acc, wf, xf);
+      phase_end();
+      issue(K2{}, t + 2);
+      if (late) wait_units_in_flight(keep);
+      phase_end();
+      quadrant_mma<1, 0>(acc, wf, xf);
+      if (!late) wait_units_in_flight(keep);
+      phase_end();
+    }
+    if (!late) phase_end();
   }
 
   // ---- epilogue: lane (c,q) of tile (nt,mt) holds out[m0 + 128wr + 16mt + c][n0 + 64wc + 16nt + 4q .. +3]
@@ -169,17 +207,24 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   }
 }
 
-template <int EPI>
-void launch(const WideArgs& a, hipStream_t st) {
+template <int EPI, bool STAGGER>
+void launch_one(const WideArgs& b, hipStream_t st) {
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)gemm_wide256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_wide256_kernel<EPI, STAGGER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_BYTES);
     done = true;
   }
+  hipLaunchKernelGGL((gemm_wide256_kernel<EPI, STAGGER>), dim3(b.tilesM * b.tilesN), dim3(512), LDS_BYTES, st, b);
+}
+template <int EPI>
+void launch(const WideArgs& a, hipStream_t st) {
+  static const int variant = [] { const char* e = getenv("HWOCR_GEMM256"); return e ? atoi(e) : 2; }();
   WideArgs b = a;
   b.tilesM = (a.M + BM - 1) / BM;
   b.tilesN = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL(gemm_wide256_kernel<EPI>, dim3(b.tilesM * b.tilesN), dim3(512), LDS_BYTES, st, b);
+  if (variant == 1) launch_one<EPI, false>(b, st);
+  else launch_one<EPI, true>(b, st);
 }
 
 }  // namespace

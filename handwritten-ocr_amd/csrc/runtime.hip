@@ -64,7 +64,7 @@ extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, con
                              (long)rows_per_img_ld * hd, (long)rows * hd, hd,   // Q [head][rows][hd]
                              (long)rows_per_img_ld * hd, (long)rows * hd, hd,   // K
                              rows_per_img_ld, (long)hd * rows, rows,            // V^T [head][hd][rows]
-                             (long)rows_per_img_ld * D, D, scale, st));
+                             (long)rows_per_img_ld * D, D, scale, 0, st));
     CHECK(hwocr_gemm_wide(ws->attn, b.proj_w, b.proj_b, ws->x, ws->x, rows, D, D, D, D, D, D, HWOCR_EPI_RESIDUAL, st));
     CHECK(hwocr_layernorm(ws->x, b.ln2_w, b.ln2_b, ws->xn, rows, D, D, D, m->eps, st));
     CHECK(hwocr_gemm_wide(ws->xn, b.fc1_w, b.fc1_b, nullptr, ws->mlp, rows, m->mlp_dim, D, D, D, m->mlp_dim, 0,
@@ -102,11 +102,11 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
     CHECK(hwocr_gemm_wide(ws->hn, L.qkv_w, L.qkv_b, nullptr, ws->qkv, rows, QW, Hd, Hd, Hd, QW, 0, HWOCR_EPI_LINEAR,
                           st));
     CHECK(hwocr_mrope_kv_prefill(ws->qkv, ws->q, Kc, Vc, pos3, m->rope_cos, m->rope_sin, rows, rows_per_seq, m->Hq,
-                                 m->Hkv, m->sec0, m->sec1, k_seq, k_head, k_seq, k_head, kv->ctx, st));
+                                 m->Hkv, m->sec0, m->sec1, k_seq, k_head, k_seq, k_head, kv->ctx, kv->tiled, st));
     CHECK(hwocr_attn_prefill(ws->q, Kc, Vc, ws->attn, seq_lens, nseq, m->Hq, m->Hq / m->Hkv, HD, max_len, 1,
                              (long)rows_per_seq * m->Hq * HD, HD, (long)m->Hq * HD,  // Q [row][Hq][128]
                              k_seq, k_head, HD, k_seq, k_head, kv->ctx,
-                             (long)rows_per_seq * m->Hq * HD, (long)m->Hq * HD, scale, st));
+                             (long)rows_per_seq * m->Hq * HD, (long)m->Hq * HD, scale, kv->tiled, st));
     CHECK(hwocr_gemm_wide(ws->attn, L.o_w, nullptr, ws->h, ws->h, rows, Hd, m->Hq * HD, m->Hq * HD, m->Hq * HD, Hd, Hd,
                           HWOCR_EPI_RESIDUAL, st));
     CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd, nullptr, rows, Hd,
@@ -146,9 +146,9 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
                             HWOCR_EPI_PARTIAL, s_qkv, L.qkv_wt != nullptr, st));
     CHECK(hwocr_decode_qkv_finish(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, ws->q, Kc, Vc, gs->lens, gs->rope_delta,
                                   m->rope_cos, m->rope_sin, nseq, m->Hq, m->Hkv, k_seq, k_head, k_seq, k_head,
-                                  kv->ctx, st));
+                                  kv->ctx, kv->tiled, st));
     CHECK(hwocr_attn_decode(ws->q, Kc, Vc, gs->lens, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv,
-                            attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, st));
+                            attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, kv->tiled, st));
     CHECK(hwocr_gemm_skinny(ws->attn, L.o_wt ? L.o_wt : L.o_w, nullptr, ws->slabs, nseq, Hd, OW, OW, OW, Hd,
                             HWOCR_EPI_PARTIAL, s_o, L.o_wt != nullptr, st));
     CHECK(hwocr_add_rmsnorm(ws->slabs, s_o, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd,

@@ -308,7 +308,7 @@ class ReadEngine:
         kv_elems = c.layers * R * c.kv_heads * self.ctx * HD
         self.k_cache = torch.zeros(kv_elems, dtype=bf, device=dev)
         self.vt_cache = torch.zeros(kv_elems, dtype=bf, device=dev)
-        self.kv = _lib.Kv(k=_lib.ptr(self.k_cache), vt=_lib.ptr(self.vt_cache), nseq_max=R, ctx=self.ctx)
+        self.kv = _lib.Kv(k=_lib.ptr(self.k_cache), vt=_lib.ptr(self.vt_cache), nseq_max=R, ctx=self.ctx, tiled=1)
         i32 = dict(dtype=torch.int32, device=dev)
         self.cur_ids = torch.zeros(R, **i32)
         self.lens = torch.zeros(R, **i32)

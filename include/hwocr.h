@@ -62,12 +62,13 @@ int hwocr_tile_weights(const void* src, void* dst, int N, int K, int ldw, hwocr_
 int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, void* O, const int* lens, int nseg, int heads,
                        int group, int head_dim, int max_len, int causal, long q_seg, long q_head, long q_row,
                        long k_seg, long k_head, long k_row, long v_seg, long v_head, long v_row, long o_seg,
-                       long o_row, float scale, hwocr_stream_t stream);
+                       long o_row, float scale, int kv_tiled, hwocr_stream_t stream);
 
-/* One query token per read against its KV cache (HF modeling_qwen2_vl.py:553-569 with q_len == 1). head_dim 128. */
+/* One query token per read against its KV cache (HF modeling_qwen2_vl.py:553-569 with q_len == 1). head_dim 128.
+ * kv_tiled (here and in the cache writers below): the cache is in the fragment-tiled layout, strides k_row/v_row unused. */
 int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out, float* part_o,
                       float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head, long v_seq,
-                      long v_head, long v_row, float scale, hwocr_stream_t stream);
+                      long v_head, long v_row, float scale, int kv_tiled, hwocr_stream_t stream);
 
 /* uint8 HWC resized pages -> bf16 patch rows (HF image_processing_pil_qwen2_vl.py:152-187, :226-229). */
 int hwocr_patchify(const void* img, const void* lut, void* out, int nimg, int H, int W, int patch, int merge,
@@ -89,12 +90,13 @@ int hwocr_vit_rope_split(const void* qkv, void* Q, void* K, void* VT, const int*
  * cache), cache slot r % rows_per_seq */
 int hwocr_mrope_kv_prefill(const void* qkv, void* Q, void* K, void* VT, const int* pos, const void* cos_tab,
                            const void* sin_tab, int rows, int rows_per_seq, int Hq, int Hkv, int sec0, int sec1,
-                           long k_seq, long k_head, long v_seq, long v_head, long v_row, hwocr_stream_t stream);
+                           long k_seq, long k_head, long v_seq, long v_head, long v_row, int kv_tiled,
+                           hwocr_stream_t stream);
 
 int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_stride, const void* bias, void* Q, void* K,
                             void* VT, const int* lens, const int* rope_delta, const void* cos_tab,
                             const void* sin_tab, int nseq, int Hq, int Hkv, long k_seq, long k_head, long v_seq,
-                            long v_head, long v_row, hwocr_stream_t stream);
+                            long v_head, long v_row, int kv_tiled, hwocr_stream_t stream);
 
 int hwocr_embed_splice(const int* ids, const int* img_row, const void* table, const void* img, void* out, int rows,
                        int D, float scale, hwocr_stream_t stream);
@@ -144,8 +146,9 @@ typedef struct {
   const void *rope_cos, *rope_sin; /* bf16 [maxpos][64] */
 } hwocr_decoder;
 
-typedef struct { /* KV cache: K [layer][seq][Hkv][ctx][128], VT [layer][seq][Hkv][128][ctx] */
-  void* k; void* vt; int nseq_max, ctx;
+typedef struct { /* KV cache: K [layer][seq][Hkv][ctx][128], VT [layer][seq][Hkv][128][ctx]; tiled != 0: every
+                  * (seq, kv head) region is stored in the fragment-tiled order of csrc/common.cuh (kv_tiled_k/_v) */
+  void* k; void* vt; int nseq_max, ctx, tiled;
 } hwocr_kv;
 
 typedef struct {

@@ -42,3 +42,45 @@ def assert_close_bf16(got: torch.Tensor, want_f32: torch.Tensor, ulps: float = 2
     assert not bad.any(), (
         f"{what}: {int(bad.sum())}/{bad.numel()} elements off; max err {float(err.max()):.4g} "
         f"at ref {float(want_f32.flatten()[err.argmax()]):.4g}")
+
+
+def _k_offsets(ctx):
+    key = torch.arange(ctx).view(-1, 1)
+    d = torch.arange(128).view(1, -1)
+    kl = key & 31
+    t = (kl >> 2) & 1
+    c = ((kl >> 3) << 2) | (kl & 3)
+    return (((((key >> 5) * 2 + t) * 4 + (d >> 5)) * 64 + ((d >> 3) & 3) * 16 + c) * 8 + (d & 7)).reshape(-1)
+
+
+def _v_offsets(ctx):
+    d = torch.arange(128).view(-1, 1)
+    key = torch.arange(ctx).view(1, -1)
+    kl = key & 31
+    return ((((key >> 5) * 8 + (d >> 4)) * 64 + (kl >> 3) * 16 + (d & 15)) * 8 + (kl & 7)).reshape(-1)
+
+
+def tile_k(k):
+    """[..., ctx, 128] row-major -> the fragment-tiled cache order (csrc/common.cuh kv_tiled_k), same shape."""
+    ctx = k.shape[-2]
+    out = torch.empty_like(k).view(*k.shape[:-2], ctx * 128)
+    out[..., _k_offsets(ctx).to(k.device)] = k.reshape(*k.shape[:-2], ctx * 128)
+    return out.view(k.shape)
+
+
+def untile_k(t):
+    ctx = t.shape[-2]
+    return t.reshape(*t.shape[:-2], ctx * 128)[..., _k_offsets(ctx).to(t.device)].view(t.shape)
+
+
+def tile_v(vt):
+    """[..., 128, ctx] row-major -> fragment-tiled (kv_tiled_v)."""
+    ctx = vt.shape[-1]
+    out = torch.empty_like(vt).view(*vt.shape[:-2], ctx * 128)
+    out[..., _v_offsets(ctx).to(vt.device)] = vt.reshape(*vt.shape[:-2], ctx * 128)
+    return out.view(vt.shape)
+
+
+def untile_v(t):
+    ctx = t.shape[-1]
+    return t.reshape(*t.shape[:-2], ctx * 128)[..., _v_offsets(ctx).to(t.device)].view(t.shape)

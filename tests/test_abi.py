@@ -31,4 +31,4 @@ def test_abi_version_and_structs():
     assert _lib.hip().hwocr_abi_version() == 1
     # layout contract with include/hwocr.h (LP64): ints, one float, then 8-byte-aligned pointers
     assert C.sizeof(_lib.Vit) == 40 + 11 * 8 and C.sizeof(_lib.Decoder) == 40 + 7 * 8 and C.sizeof(_lib.DecLayer) == 11 * 8
-    assert C.sizeof(_lib.GenState) == 6 * 8 + 8 * 4 and C.sizeof(_lib.Kv) == 24
+    assert C.sizeof(_lib.GenState) == 6 * 8 + 8 * 4 and C.sizeof(_lib.Kv) == 32

@@ -8,7 +8,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests._gpu_util import DEV, assert_close_bf16, lib, p, randbf, rbf, st  # noqa: E402
+from tests._gpu_util import (DEV, assert_close_bf16, lib, p, randbf, rbf, st, tile_k, tile_v, untile_k,  # noqa: E402
+                             untile_v)
 
 
 def sync():
@@ -144,9 +145,9 @@ def _sdpa_ref(q, k, v, causal, scale):
     return (torch.softmax(s, -1) @ v).permute(1, 0, 2)
 
 
-@pytest.mark.parametrize("hd,Hq,Hkv,causal", [(80, 4, 4, False), (128, 6, 2, True), (32, 2, 2, False),
-                                               (64, 2, 1, True), (128, 2, 2, False)])
-def test_attn_prefill(hd, Hq, Hkv, causal):
+@pytest.mark.parametrize("hd,Hq,Hkv,causal,tiled", [(80, 4, 4, False, 0), (128, 6, 2, True, 0), (32, 2, 2, False, 0),
+                                                     (64, 2, 1, True, 0), (128, 2, 2, False, 0), (128, 6, 2, True, 1)])
+def test_attn_prefill(hd, Hq, Hkv, causal, tiled):
     lens = [300, 64, 37, 129]
     nseg, Lp = len(lens), 320  # per-segment stride, multiple of 64
     q = randbf(nseg, Lp, Hq, hd, seed=12)
@@ -160,9 +161,10 @@ def test_attn_prefill(hd, Hq, Hkv, causal):
     out = torch.zeros(nseg, Lp, Hq * hd, dtype=torch.bfloat16, device=DEV)
     lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
     scale = hd ** -0.5
-    rc = lib().hwocr_attn_prefill(p(q), p(k), p(vt), p(out), p(lens_d), nseg, Hq, Hq // Hkv, hd, max(lens), int(causal),
+    kk, vv = (tile_k(k), tile_v(vt)) if tiled else (k, vt)
+    rc = lib().hwocr_attn_prefill(p(q), p(kk), p(vv), p(out), p(lens_d), nseg, Hq, Hq // Hkv, hd, max(lens), int(causal),
                                   Lp * Hq * hd, hd, Hq * hd, Hkv * Lp * hd, Lp * hd, hd,
-                                  Hkv * hd * Lp, hd * Lp, Lp, Lp * Hq * hd, Hq * hd, scale, st())
+                                  Hkv * hd * Lp, hd * Lp, Lp, Lp * Hq * hd, Hq * hd, scale, tiled, st())
     assert rc == 0
     sync()
     for s, n in enumerate(lens):
@@ -174,8 +176,9 @@ def test_attn_prefill(hd, Hq, Hkv, causal):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize("tiled", [0, 1])
 @pytest.mark.parametrize("nsplit", [1, 4])
-def test_attn_decode(nsplit):
+def test_attn_decode(nsplit, tiled):
     Hq, Hkv, hd, ctx = 12, 2, 128, 640
     lens = [1, 63, 64, 65, 500, 640]
     B = len(lens)
@@ -191,8 +194,9 @@ def test_attn_decode(nsplit):
     part_o = torch.zeros(B * Hkv * nsplit * G * hd, dtype=torch.float32, device=DEV)
     part_ml = torch.zeros(B * Hkv * nsplit * G * 2, dtype=torch.float32, device=DEV)
     lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
-    rc = lib().hwocr_attn_decode(p(q), p(k), p(vt), p(lens_d), p(out), p(part_o), p(part_ml), B, Hq, Hkv, nsplit,
-                                 Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, st())
+    kk, vv = (tile_k(k), tile_v(vt)) if tiled else (k, vt)
+    rc = lib().hwocr_attn_decode(p(q), p(kk), p(vv), p(lens_d), p(out), p(part_o), p(part_ml), B, Hq, Hkv, nsplit,
+                                 Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, tiled, st())
     assert rc == 0
     sync()
     for b, n in enumerate(lens):
@@ -337,7 +341,8 @@ def _rope_tables(maxpos, theta=1e6):
     return fr.cos().to(torch.bfloat16), fr.sin().to(torch.bfloat16)
 
 
-def test_mrope_kv_prefill():
+@pytest.mark.parametrize("tiled", [0, 1])
+def test_mrope_kv_prefill(tiled):
     Hq, Hkv, nseq, Tp, ctx = 4, 2, 2, 128, 256
     rows = nseq * Tp
     W = (Hq + 2 * Hkv) * 128
@@ -351,9 +356,11 @@ def test_mrope_kv_prefill():
     pos_d, cos_d, sin_d = pos3.to(DEV), cos_t.to(DEV), sin_t.to(DEV)
     rc = lib().hwocr_mrope_kv_prefill(p(qkv), p(Q), p(Kc), p(VT), p(pos_d), p(cos_d), p(sin_d),
                                       rows, Tp, Hq, Hkv, 16, 40, Hkv * ctx * 128, ctx * 128, Hkv * 128 * ctx, 128 * ctx,
-                                      ctx, st())
+                                      ctx, tiled, st())
     assert rc == 0
     sync()
+    if tiled:
+        Kc, VT = untile_k(Kc), untile_v(VT)
     x = qkv.float().cpu()
     qw = _mrope_ref(x[:, : Hq * 128].view(rows, Hq, 128), pos3, cos_t, sin_t, 16, 40)
     kw = _mrope_ref(x[:, Hq * 128: (Hq + Hkv) * 128].view(rows, Hkv, 128), pos3, cos_t, sin_t, 16, 40)
@@ -363,7 +370,8 @@ def test_mrope_kv_prefill():
     assert torch.equal(VT[:, :, :, :Tp].cpu(), vw)
 
 
-def test_decode_qkv_finish():
+@pytest.mark.parametrize("tiled", [0, 1])
+def test_decode_qkv_finish(tiled):
     Hq, Hkv, B, ctx, nslab = 12, 2, 5, 256, 3
     W = (Hq + 2 * Hkv) * 128
     slabs = torch.randn(nslab, B, W, device=DEV)
@@ -377,9 +385,11 @@ def test_decode_qkv_finish():
     lens_d, delta_d, cos_d, sin_d = lens.to(DEV), delta.to(DEV), cos_t.to(DEV), sin_t.to(DEV)
     rc = lib().hwocr_decode_qkv_finish(p(slabs), nslab, B * W, p(bias), p(Q), p(Kc), p(VT), p(lens_d),
                                        p(delta_d), p(cos_d), p(sin_d), B, Hq, Hkv,
-                                       Hkv * ctx * 128, ctx * 128, Hkv * 128 * ctx, 128 * ctx, ctx, st())
+                                       Hkv * ctx * 128, ctx * 128, Hkv * 128 * ctx, 128 * ctx, ctx, tiled, st())
     assert rc == 0
     sync()
+    if tiled:
+        Kc, VT = untile_k(Kc), untile_v(VT)
     row = rbf((slabs.sum(0) + bias.float()).cpu())
     pos = (lens - 1 + delta)
     pos3 = pos.unsqueeze(0).expand(3, B)
