@@ -13,6 +13,7 @@
 //                 with the usual (m, l, O) rule.
 #include "common.cuh"
 #include "hwocr.h"
+#include <cstdlib>
 
 namespace {
 
@@ -234,6 +235,195 @@ int launch_prefill(const PrefillArgs& a, int nseg, int heads, int max_len, hipSt
 }
 
 // ------------------------------------------------------------------------------------------------
+// Vision-tower specialisation: head_dim 80, non-causal, row-major K / V^T (the hot attention of a page read:
+// 16 heads x 5184 tokens x 32 layers per read).  Same mathematics as attn_prefill_kernel<80,false>, re-tiled for
+// occupancy and VALU load:
+//   * K / V^T tiles are staged by LDS-DMA (no staging registers, no ds_write): 3 workgroups per CU instead of 2.
+//     LDS images are lane-linear per DMA instruction, so the bank swizzle is applied to the SOURCE address:
+//       K  d 0..63  : [64 keys][128 B], chunk p of row r holds chunk p ^ ((r>>1)&7)
+//       K  d 64..79 : [64 keys][ 32 B], chunk p of row r holds chunk p ^ ((r>>3)&1)
+//       V^T         : [88 d   ][128 B], chunk p of row d holds chunk p ^ ((d>>1)&7); row 80 is all ones, so the
+//                     padded third d-tile of the PV product accumulates the softmax denominator on the matrix pipe
+//                     (the sum of the bf16-rounded weights, i.e. exactly the weights that multiply V) — 32 VALU adds
+//                     per tile less, and the running-max rescale covers it for free.
+//   * row max through v_max3 (fmaxf nests), exp2 of fma(score, scale, -max).
+// ------------------------------------------------------------------------------------------------
+constexpr int V80_K0 = 64 * 128, V80_K1 = 64 * 32, V80_VT = 88 * 128;
+constexpr int V80_STAGE = V80_K0 + V80_K1 + V80_VT;  // 21504 B
+
+__global__ __launch_bounds__(256, 3) void attn_vit80_kernel(PrefillArgs a) {
+  constexpr int HD = 80;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages
+  const int seg = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+  const int len = a.lens[seg];
+  if (q0 >= len) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const bf16* Qp = a.Q + seg * a.q_seg + h * a.q_head;
+  const bf16* Kp = a.K + seg * a.k_seg + h * a.k_head;
+  const bf16* Vp = a.VT + seg * a.v_seg + h * a.v_head;
+  const int qi = q0 + 32 * w + r;
+  const int rk = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);  // tile row -> key permutation (bits 2,3 swapped)
+
+  bf16x8 qf[5];
+  {
+    const bf16* qrow = Qp + (long)min(qi, len - 1) * a.q_row + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) qf[s] = *(const bf16x8*)(qrow + 16 * s);
+  }
+  // V^T rows 80..87 of both stages: row 80 = 1.0, the rest 0 (never touched by the DMA)
+  for (int i = tid; i < 2 * 8 * 64; i += 256) {
+    const int stg = i >> 9, rr = (i >> 6) & 7, col = i & 63;
+    ((bf16*)(smem + stg * V80_STAGE + V80_K0 + V80_K1 + (80 + rr) * 128))[col] = (bf16)(rr == 0 ? 1.0f : 0.0f);
+  }
+
+  // DMA plan per tile: 20 instructions, 5 per wave:  K0: 8 (2 per wave), K1: 2 (waves 0,1), V^T: 10 (2,2,3,3)
+  const int nt = (len + 63) >> 6;
+  auto stage_tile = [&](int t) {
+    const int j0 = t * 64;
+    char* st = smem + (t & 1) * V80_STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // K d 0..63: 8 rows per instruction
+      const int row = 8 * (2 * w + i) + (lane >> 3);
+      const int lc = (lane & 7) ^ ((row >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((const void*)(Kp + (long)min(j0 + row, len - 1) * a.k_row + lc * 8),
+                                       LDS_PTR(st + (2 * w + i) * 1024), 16, 0, 0);
+    }
+    if (w < 2) {  // K d 64..79: 32 rows per instruction
+      const int row = 32 * w + (lane >> 1);
+      const int lc = (lane & 1) ^ ((row >> 3) & 1);
+      __builtin_amdgcn_global_load_lds((const void*)(Kp + (long)min(j0 + row, len - 1) * a.k_row + 64 + lc * 8),
+                                       LDS_PTR(st + V80_K0 + w * 1024), 16, 0, 0);
+    }
+    const int v0 = w < 2 ? 2 * w : 4 + 3 * (w - 2), vn = w < 2 ? 2 : 3;  // V^T: 8 d rows per instruction
+    for (int i = 0; i < vn; ++i) {
+      const int d = 8 * (v0 + i) + (lane >> 3);
+      const int lc = (lane & 7) ^ ((d >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((const void*)(Vp + (long)d * a.v_row + j0 + lc * 8),
+                                       LDS_PTR(st + V80_K0 + V80_K1 + (v0 + i) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 o[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  float m = NEG_BIG;
+
+  stage_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int j0 = t * 64;
+    char* st = smem + (t & 1) * V80_STAGE;
+    if (t + 1 < nt) stage_tile(t + 1);
+    if (j0 + 64 > len) {
+      // tail tile: keys past the segment must contribute 0 * finite.  Their scores are masked below; their V^T columns
+      // are whatever the buffer holds, so clear them in LDS (one extra barrier, last tile only).
+      for (int i = tid; i < 80 * 64; i += 256) {
+        const int d = i >> 6, col = i & 63;
+        if (j0 + col >= len) {
+          const int ch = (col >> 3) ^ ((d >> 1) & 7);
+          ((bf16*)(st + V80_K0 + V80_K1 + d * 128 + ch * 16))[col & 7] = (bf16)0.0f;
+        }
+      }
+      __syncthreads();
+    }
+    const char* k0b = st;
+    const char* k1b = st + V80_K0;
+    const char* vb = st + V80_K0 + V80_K1;
+
+    f32x16 s0, s1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ra = rk, rb = 32 + rk;
+      const bf16x8 ka = *(const bf16x8*)(k0b + ra * 128 + (((2 * s + hh) ^ ((ra >> 1) & 7)) << 4));
+      const bf16x8 kb2 = *(const bf16x8*)(k0b + rb * 128 + (((2 * s + hh) ^ ((rb >> 1) & 7)) << 4));
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qf[s], s1, 0, 0, 0);
+    }
+    {
+      const int ra = rk, rb = 32 + rk;
+      const bf16x8 ka = *(const bf16x8*)(k1b + ra * 32 + ((hh ^ ((ra >> 3) & 1)) << 4));
+      const bf16x8 kb2 = *(const bf16x8*)(k1b + rb * 32 + ((hh ^ ((rb >> 3) & 1)) << 4));
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[4], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2, qf[4], s1, 0, 0, 0);
+    }
+    if (j0 + 64 > len) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = j0 + 16 * (i >> 3) + 8 * hh + (i & 7);
+        if (key >= len) s0[i] = -INFINITY;
+        if (key + 32 >= len) s1[i] = -INFINITY;
+      }
+    }
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s0[i]), s1[i]);  // v_max3_f32
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;
+    if (__any(mx > m)) {
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      m = m_new;
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    }
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pb[0][s2][j] = f2bf(__builtin_amdgcn_exp2f(__builtin_fmaf(s0[8 * s2 + j], a.scale_log2, -m)));
+        pb[1][s2][j] = f2bf(__builtin_amdgcn_exp2f(__builtin_fmaf(s1[8 * s2 + j], a.scale_log2, -m)));
+      }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int row = d * 32 + r;  // rows >= 88 of the last d-tile read past the V^T image: unused accumulator rows
+          const bf16x8 vf = *(const bf16x8*)(vb + row * 128 + (((kt * 4 + s2 * 2 + hh) ^ ((row >> 1) & 7)) << 4));
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt][s2], o[d], 0, 0, 0);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // softmax denominator = accumulator row d = 80 (d-tile 2, local row 16 -> register 8 of the hh = 0 half)
+  const float l = __shfl(o[2][8], r);
+  const float inv = 1.0f / l;
+  if (qi < len) {
+    bf16* orow = a.O + seg * a.o_seg + (long)qi * a.o_row + h * HD;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * hh;
+        if (dd < HD) {
+          bf16x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[d][4 * g + e] * inv);
+          *(bf16x4*)(orow + dd) = ov;
+        }
+      }
+  }
+}
+
+int launch_vit80(const PrefillArgs& a, int nseg, int heads, int max_len, hipStream_t st) {
+  constexpr int LDS = 2 * V80_STAGE;
+  dim3 grid((max_len + 127) / 128, heads, nseg), block(256);
+  hipLaunchKernelGGL(attn_vit80_kernel, grid, block, LDS, st, a);
+  return hwocr_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // decode attention
 // ------------------------------------------------------------------------------------------------
 struct DecodeArgs {
@@ -412,6 +602,10 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
                 q_seg, q_head, q_row, k_seg, k_head, k_row, v_seg, v_head, v_row, o_seg, o_row,
                 group, scale * 1.4426950408889634f, kv_tiled};
   if (kv_tiled && head_dim != 128) return HWOCR_EINVAL;
+  if (head_dim == 80 && !causal && group == 1) {
+    static const bool generic = [] { const char* e = getenv("HWOCR_ATTN_GENERIC"); return e && atoi(e) != 0; }();
+    if (!generic) return launch_vit80(a, nseg, heads, max_len, stream);
+  }
   if (head_dim == 80) return causal ? launch_prefill<80, true>(a, nseg, heads, max_len, stream)
                                     : launch_prefill<80, false>(a, nseg, heads, max_len, stream);
   if (head_dim == 128) return causal ? launch_prefill<128, true>(a, nseg, heads, max_len, stream)
