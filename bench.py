@@ -172,7 +172,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pages", type=int, default=32, help="pages per step per GPU (x3 reads in flight)")
+    ap.add_argument("--pages", type=int, default=42, help="pages per step per GPU (x3 reads in flight, <= 128 reads)")
     ap.add_argument("--reads", type=int, default=3)
     ap.add_argument("--new-tokens", type=int, default=512)
     ap.add_argument("--side", type=int, default=1024)
@@ -253,6 +253,14 @@ def main() -> None:
     per_layer = (cfg.q_heads + 2 * cfg.kv_heads) * 128 * cfg.hidden + cfg.q_heads * 128 * cfg.hidden + 3 * cfg.inter * cfg.hidden
     w_bytes = 2.0 * (cfg.layers * per_layer + cfg.vocab * cfg.hidden)
     kv_bytes = n_reads * cfg.layers * 2 * cfg.kv_heads * 128 * 2 * (T + args.new_tokens / 2)
+    # HBM-side traffic of the dominant kernel: not measurable in-process — taken from the committed summary of separate
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (tools/pmc_summary.py, corrections stated there)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f)["kernels"]["gemm_wide256_kernel"]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "handwritten pages/sec (1024x1024, 3-strategy reads)", "value": value, "unit": "pages/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -262,9 +270,11 @@ def main() -> None:
                    "pages_per_step_per_gpu": args.pages, "reads_in_flight": n_reads, "prompt_tokens": T,
                    "image_tokens": int((prompts[0] == cfg.image_token_id).sum()), "new_tokens": args.new_tokens,
                    "parallelism": f"replicas x{world}, pages sharded, RCCL gather of token streams"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_wide_kernel (bf16 128x128x64 MFMA GEMM)", "achieved": achieved,
-                     "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "launches": int(n.value), "avg_launch_ms": ms.value / max(1, n.value),
+        "roofline": {"bound": "mfma", "kernel": "gemm_wide256_kernel (bf16 256x256x64 MFMA GEMM, 8 waves, staggered phases)",
+                     "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_note": "bytes per launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)",
+                     "launches": int(n.value), "avg_launch_ms": ms.value / max(1, n.value),
                      "algorithmic_flops_per_launch": fl.value / max(1, n.value),
                      "share_of_step_time": ms.value / (elapsed * 1e3)},
         "phases_ms_per_step": {"vision": mean("vision_ms"), "prefill": mean("prefill_ms"), "decode": mean("decode_ms"),

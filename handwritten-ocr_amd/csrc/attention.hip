@@ -28,6 +28,7 @@ struct PrefillArgs {
   int group;          // query heads per kv head
   float scale_log2;   // softmax scale * log2(e)
   int kv_tiled;       // K / V^T in the fragment-tiled cache layout (common.cuh) instead of rows
+  int heads, nseg, qblocks;  // 1-D grid decomposition (attn_vit80_kernel)
 };
 
 __device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
@@ -254,7 +255,25 @@ constexpr int V80_STAGE = V80_K0 + V80_K1 + V80_VT;  // 21504 B
 __global__ __launch_bounds__(256, 3) void attn_vit80_kernel(PrefillArgs a) {
   constexpr int HD = 80;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages
-  const int seg = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128;
+  // 1-D grid of qblocks x (head, page) pairs.  Consecutive block ids go to different XCDs, so give every XCD whole
+  // (head, page) pairs: all query blocks that re-read one K / V^T then share one L2 (measured before: 5x the unique
+  // K/V bytes crossed the fabric).  Speed only.
+  int seg, h, q0;
+  {
+    const int npairs = a.heads * a.nseg, L = blockIdx.x;
+    int pair, qb;
+    if ((npairs & 7) == 0) {
+      const int slot = L >> 3;
+      pair = (slot / a.qblocks) * 8 + (L & 7);
+      qb = slot % a.qblocks;
+    } else {
+      pair = L / a.qblocks;
+      qb = L % a.qblocks;
+    }
+    seg = pair / a.heads;
+    h = pair % a.heads;
+    q0 = qb * 128;
+  }
   const int len = a.lens[seg];
   if (q0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -418,8 +437,11 @@ __global__ __launch_bounds__(256, 3) void attn_vit80_kernel(PrefillArgs a) {
 
 int launch_vit80(const PrefillArgs& a, int nseg, int heads, int max_len, hipStream_t st) {
   constexpr int LDS = 2 * V80_STAGE;
-  dim3 grid((max_len + 127) / 128, heads, nseg), block(256);
-  hipLaunchKernelGGL(attn_vit80_kernel, grid, block, LDS, st, a);
+  PrefillArgs b = a;
+  b.heads = heads;
+  b.nseg = nseg;
+  b.qblocks = (max_len + 127) / 128;
+  hipLaunchKernelGGL(attn_vit80_kernel, dim3(b.qblocks * heads * nseg), dim3(256), LDS, st, b);
   return hwocr_launch_status();
 }
 
@@ -600,7 +622,7 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
     return HWOCR_EINVAL;
   PrefillArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, (bf16*)O, lens,
                 q_seg, q_head, q_row, k_seg, k_head, k_row, v_seg, v_head, v_row, o_seg, o_row,
-                group, scale * 1.4426950408889634f, kv_tiled};
+                group, scale * 1.4426950408889634f, kv_tiled, heads, nseg, (max_len + 127) / 128};
   if (kv_tiled && head_dim != 128) return HWOCR_EINVAL;
   if (head_dim == 80 && !causal && group == 1) {
     static const bool generic = [] { const char* e = getenv("HWOCR_ATTN_GENERIC"); return e && atoi(e) != 0; }();

@@ -359,7 +359,7 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
              M, N, K, ldx, ldw, ldo, ldres, (M + BM - 1) / BM, (N + BN - 1) / BN};
   const bool prof = g_prof.on && g_prof.n < PROF_CAP;
   static const bool use256 = [] { const char* e = getenv("HWOCR_GEMM256"); return !e || atoi(e) != 0; }();
-  if (use256 && M >= 1024 && N >= 256) {
+  if (use256 && M >= 1024 && N >= 256 && (ldo % 8) == 0 && (epi != EPI_RESIDUAL || (ldres % 8) == 0)) {
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
     const int rc = hwocr_gemm_wide256(a, epi, stream);
     if (prof) {

@@ -194,15 +194,57 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   }
 
   // ---- epilogue: lane (c,q) of tile (nt,mt) holds out[m0 + 128wr + 16mt + c][n0 + 64wc + 16nt + 4q .. +3]
+  if constexpr (EPI == EPI_SWIGLU) {
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const int m = m0 + 128 * wr + 16 * mt + c;
-    if constexpr (EPI == EPI_SWIGLU) {
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = m0 + 128 * wr + 16 * mt + c;
 #pragma unroll
       for (int nt = 0; nt < 4; nt += 2) store_swiglu(a, acc[nt][mt], acc[nt + 1][mt], m, n0 + 64 * wc + 16 * nt, q);
-    } else {
+    }
+  } else {
+    // Through LDS so that HBM sees whole 128-byte rows: the fragment layout gives a lane 8 bytes of 16 different rows
+    // per store (32 store instructions per wave, 16 partial lines each); staged, a wave stores its 128 x 64 block as
+    // 16 instructions of 8 full rows.  Every wave uses a private 16 KiB of the (now idle) operand stages; the
+    // last phase_end() of the main loop is the barrier that frees them.
+    char* ep = smem + w * 16384;  // [128 rows][128 B], 16-byte chunk p of row r at p ^ (r & 7)
+    bf16x4 bv[4];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) store_tile<EPI>(a, acc[nt][mt], m, n0 + 64 * wc + 16 * nt + 4 * q);
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + 64 * wc + 16 * nt + 4 * q;
+      bv[nt] = (a.bias && n < a.N) ? *(const bf16x4*)(a.bias + n) : bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int ml = 16 * mt + c;
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[nt][mt][r] + bf2f(bv[nt][r]);
+          if constexpr (EPI == EPI_QUICKGELU) v = act_quick_gelu(rbf(v));
+          else if constexpr (EPI == EPI_GELU) v = act_gelu_erf(rbf(v));
+          o[r] = f2bf(v);
+        }
+        *(bf16x4*)(ep + ml * 128 + (((2 * nt + (q >> 1)) ^ (ml & 7)) << 4) + (q & 1) * 8) = o;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own wave's writes are in LDS before any lane reads them
+    __builtin_amdgcn_wave_barrier();
+    const int pch = lane & 7;
+    const int n = n0 + 64 * wc + 8 * pch;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 8 * i + (lane >> 3);
+      const int m = m0 + 128 * wr + row;
+      bf16x8 v = *(const bf16x8*)(ep + row * 128 + ((pch ^ (row & 7)) << 4));
+      if (m < a.M && n < a.N) {
+        if constexpr (EPI == EPI_RESIDUAL) {
+          const bf16x8 rs = *(const bf16x8*)(a.res + (size_t)m * a.ldres + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rs[e]));
+        }
+        *(bf16x8*)(a.out + (size_t)m * a.ldo + n) = v;
+      }
     }
   }
 }
