@@ -144,6 +144,13 @@ def run_graph(state: dict) -> dict:
     last-write-wins merge of partial updates (graph.py:49-79: TypedDict state, no reducers)."""
     state = dict(state)
     state.update(node_initial_ocr(state))
+    return run_graph_after_initial(state)
+
+
+def run_graph_after_initial(state: dict) -> dict:
+    """critic -> {accept | plateau | max_iterations | reocr | edit} ... -> END, for a state that already went through
+    `initial_ocr` (the batched driver computes that node for many pages at once)."""
+    state = dict(state)
     while True:
         state.update(node_critic(state))
         step = route_after_critic(state)

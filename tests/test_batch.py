@@ -1,0 +1,82 @@
+"""Batch-folder driver: one batched engine pass for all pages, then the reference's per-page node logic and output files.
+The engine is replaced by a scripted `run_ocr_batch` (CPU test); the node logic itself is pinned by tests/test_nodes.py."""
+import contextlib
+import io
+import json
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from handwritten_ocr_amd import batch, tools
+from handwritten_ocr_amd.compat import config, nodes
+from handwritten_ocr_amd.compat.state import new_state
+from handwritten_ocr_amd.synth import make_page
+
+
+def _pages(tmp_path, n):
+    paths = []
+    for i in range(n):
+        p = tmp_path / f"page{i:02d}.png"
+        Image.fromarray(make_page(i, 64, 64), "RGB").save(p)
+        paths.append(p)
+    (tmp_path / "notes.txt").write_text("not an image")
+    return paths
+
+
+def test_batched_initial_ocr_equals_serial_node(tmp_path, monkeypatch):
+    paths = _pages(tmp_path, 3)
+    # page 0: reads agree -> the speculative third read must not be consumed; pages 1, 2: disagreement -> tie-breaker
+    script = {0: ["same text here", "same text here", "UNUSED"], 1: ["alpha beta gamma delta", "completely different words", "alpha beta gamma"],
+              2: ["x y z", "p q r s t", "x y z w"]}
+    calls = []
+
+    def fake_batch(images, params=None):
+        calls.append(len(images))
+        assert all(isinstance(im, Image.Image) for im in images)
+        return [script[i // 3][i % 3] for i in range(len(images))]
+
+    monkeypatch.setattr(tools, "run_ocr_batch", fake_batch)
+    with contextlib.redirect_stdout(io.StringIO()):
+        states = batch.initial_ocr_batched([str(p) for p in paths])
+    assert calls == [9]  # ONE engine pass for 3 pages x 3 strategies
+    for i, st in enumerate(states):
+        # serial reference path: the same node with per-read fakes
+        it = iter(script[i])
+        monkeypatch.setattr(nodes, "run_ocr", lambda path, params=None, _it=it: next(_it))
+        monkeypatch.setattr(nodes, "preprocess_image", lambda path, s: path)
+        monkeypatch.setattr(nodes, "unload_ocr_model", lambda: None)
+        serial = new_state(str(paths[i]), config)
+        with contextlib.redirect_stdout(io.StringIO()):
+            serial.update(nodes.node_initial_ocr(serial))
+        assert st["current_best"] == serial["current_best"]
+        assert [c["text"] for c in st["candidates"]] == [c["text"] for c in serial["candidates"]]
+        assert st["strategies_used"] == serial["strategies_used"]
+        strip = lambda ev: {k: v for k, v in ev.items() if k not in ("timestamp", "elapsed_seconds", "input_summary")}
+        assert [strip(e) for e in st["trace_events"]] == [strip(e) for e in serial["trace_events"]]
+    assert len(states[0]["candidates"]) == 2 and len(states[1]["candidates"]) == 3
+
+
+def test_folder_outputs(tmp_path, monkeypatch):
+    paths = _pages(tmp_path, 2)
+    gtd = tmp_path / "gt"
+    gtd.mkdir()
+    (gtd / "page00.md").write_text("# doc\n\n## Ground Truth\n\nhello world\n")
+    monkeypatch.setattr(tools, "run_ocr_batch", lambda images, params=None: ["hello world"] * len(images))
+    assert [p.name for p in batch.list_images(tmp_path)] == ["page00.png", "page01.png"]
+    out_dir = tmp_path / "results"
+    outs = batch.transcribe_folder(batch.list_images(tmp_path), out_dir, gtd, quiet=True)
+    assert [o.name for o in outs] == ["page00_transcription.txt", "page01_transcription.txt"]
+    assert outs[0].read_text() == "hello world"
+    ev = json.loads((out_dir / "page00_trace.json").read_text())
+    assert [e["action"] for e in ev] == ["preprocess", "ocr", "preprocess", "ocr", "compare", "merge"]
+    summary = (out_dir / "page00_trace_summary.txt").read_text().splitlines()
+    assert len(summary) == len(ev) and summary[-1].endswith("Merged → 11 chars")
+    e0 = json.loads((out_dir / "page00_eval.json").read_text())
+    assert e0["tier1_raw_vs_gt"]["cer"] == 0.0 and e0["pipeline_status"] == "initial_ocr"
+    assert "tier1_raw_vs_gt" not in json.loads((out_dir / "page01_eval.json").read_text())
+
+
+def test_cli_rejects_missing_input(tmp_path):
+    with pytest.raises(SystemExit):
+        batch.main([str(tmp_path / "nope")])

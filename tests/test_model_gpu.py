@@ -107,3 +107,44 @@ def test_eos_stops_a_read(eng):
         eng.cfg.eos_ids = old
     first = free.index(free[3])
     assert out == free[: first + 1]
+
+
+def test_drop_in_tools_surface(tmp_path, monkeypatch, capsys):
+    """run_ocr / run_ocr_batch / unload_ocr_model with the reference's signatures and prints, through the compat node."""
+    from handwritten_ocr_amd import tools
+    from handwritten_ocr_amd.compat import config, nodes
+    from handwritten_ocr_amd.compat.state import new_state
+    from handwritten_ocr_amd.synth import make_page
+
+    monkeypatch.setenv("HWOCR_MODEL", "tiny")
+    monkeypatch.setenv("HWOCR_MAX_READS", "8")
+    monkeypatch.setenv("HWOCR_CTX", "512")
+    monkeypatch.setattr(tools, "_ocr_model", None)
+    monkeypatch.setattr(tools, "_ocr_processor", None)
+    monkeypatch.setattr(config, "OCR_MIN_PIXELS", 28 * 28)  # keep the tiny model's prompt short
+    paths = []
+    for i in range(2):
+        p = tmp_path / f"p{i}.png"
+        Image.fromarray(make_page(40 + i, 70, 100), "RGB").save(p)
+        paths.append(str(p))
+    params = {"max_new_tokens": 12, "min_new_tokens": 12}
+    one = [tools.run_ocr(p, params) for p in paths]
+    out = capsys.readouterr().out
+    assert "  [ocr] Loading tiny on cuda..." in out and "  [ocr] Model loaded." in out
+    assert f"  [ocr] Running OCR on p0.png..." in out and f"  [ocr] Done ({len(one[0])} chars)" in out
+    assert all(isinstance(t, str) for t in one)
+    both = tools.run_ocr_batch(paths, params)
+    assert both == one, "a read must not depend on what else is in its batch"
+    model_before = tools._ocr_model
+    assert tools.unload_ocr_model() is None
+    assert "  [ocr] Model unloaded, memory freed." in capsys.readouterr().out
+    assert tools._ocr_model is model_before  # weights stay resident by default
+    # the hot-path node on top of the real engine
+    monkeypatch.setattr(nodes, "run_ocr", lambda path, p=None: tools.run_ocr(path, params))
+    state = new_state(paths[0], config)
+    upd = nodes.node_initial_ocr(state)
+    assert len(upd["candidates"]) in (2, 3) and isinstance(upd["current_best"], str)
+    assert [e["action"] for e in upd["trace_events"]][:5] == ["preprocess", "ocr", "preprocess", "ocr", "compare"]
+    monkeypatch.setenv("HWOCR_KEEP_RESIDENT", "0")
+    tools.unload_ocr_model()
+    assert tools._ocr_model is None
