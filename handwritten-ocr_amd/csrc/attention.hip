@@ -462,11 +462,13 @@ constexpr int DEC_HD = 128;
 // Keys are walked in blocks of 32.  MFMA tile rows are assigned to keys so that the score registers a lane ends up with
 // are 8 CONSECUTIVE keys (tile t, row 4a+r <-> key 8a + 4t + r): packed to bf16 they are the B operand of the PV product
 // in natural k order, and the matching A operand is one 16-byte load of a V^T row.
-template <bool TILED>
-__global__ __launch_bounds__(256, 3) void attn_decode_kernel(DecodeArgs a) {
-  __shared__ float s_o[4][DEC_HD][16];
-  __shared__ float s_m[4][16];
-  __shared__ float s_l[4][16];
+// WAVES = 4: keys also split over `nsplit` workgroups (few reads in flight), partials merged by attn_decode_merge_kernel;
+// WAVES = 8: one workgroup per (read, kv head) walks the whole cache and writes the final output - no merge launch.
+template <bool TILED, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 3) void attn_decode_kernel(DecodeArgs a) {
+  __shared__ float s_o[WAVES][DEC_HD][16];
+  __shared__ float s_m[WAVES][16];
+  __shared__ float s_l[WAVES][16];
   const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, qd = lane >> 4;
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(DecodeArgs a) {
 
   const int krow = 8 * (c >> 2) + (c & 3);  // key (within the block) of tile-0 row c; tile 1: +4
   const int nblk = (len + 31) >> 5;
-  for (int kb = split * 4 + w; kb < nblk; kb += a.nsplit * 4) {
+  for (int kb = split * WAVES + w; kb < nblk; kb += a.nsplit * WAVES) {
     const int k0 = kb * 32;
     bf16x8 kf[2][4], vt[8];
     if constexpr (TILED) {  // one contiguous KiB per fragment, the cache is stored in operand order
@@ -570,12 +572,14 @@ __global__ __launch_bounds__(256, 3) void attn_decode_kernel(DecodeArgs a) {
     for (int e = 0; e < 4; ++e) s_o[w][16 * d + 4 * qd + e][c] = o[d][e];
   if (qd == 0) { s_m[w][c] = m; s_l[w][c] = l; }
   __syncthreads();
-  for (int idx = tid; idx < a.G * DEC_HD; idx += 256) {
+  for (int idx = tid; idx < a.G * DEC_HD; idx += 64 * WAVES) {
     const int qq = idx / DEC_HD, d = idx % DEC_HD;
-    float M = fmaxf(fmaxf(s_m[0][qq], s_m[1][qq]), fmaxf(s_m[2][qq], s_m[3][qq]));
+    float M = s_m[0][qq];
+#pragma unroll
+    for (int ww = 1; ww < WAVES; ++ww) M = fmaxf(M, s_m[ww][qq]);
     float L = 0.f, O = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww) {
+    for (int ww = 0; ww < WAVES; ++ww) {
       const float f = __builtin_amdgcn_exp2f(s_m[ww][qq] - M);
       L += s_l[ww][qq] * f;
       O += s_o[ww][d][qq] * f;
@@ -649,8 +653,14 @@ extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, c
   if ((v_row % 64) || (k_seq % 8) || (k_head % 8) || (v_seq % 8) || (v_head % 8)) return HWOCR_EINVAL;
   DecodeArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, lens, part_o, part_ml, (bf16*)out,
                k_seq, k_head, v_seq, v_head, v_row, Hq, Hkv, Hq / Hkv, nsplit, scale * 1.4426950408889634f, kv_tiled};
-  if (kv_tiled) hipLaunchKernelGGL(attn_decode_kernel<true>, dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(attn_decode_kernel<false>, dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+  if (nsplit == 1) {
+    if (kv_tiled) hipLaunchKernelGGL((attn_decode_kernel<true, 8>), dim3(1, Hkv, nseq), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<false, 8>), dim3(1, Hkv, nseq), dim3(512), 0, stream, a);
+  } else if (kv_tiled) {
+    hipLaunchKernelGGL((attn_decode_kernel<true, 4>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((attn_decode_kernel<false, 4>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+  }
   if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(Hkv, nseq), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }

@@ -198,17 +198,25 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_skinny_kernel(SkinnyArgs a) {
     if (ci + 1 < nchunk) issue(nxt, ci + 1);
     const char* xb = smem + (ci & 1) * XBYTES;
     const int nks = min(KS, (kend - (kbeg + ci * KC)) >> 5);
+    // activation fragments of k-step s+1 are fetched from LDS while k-step s is multiplied
+    bf16x8 xf[2][NB];
+    auto read_x = [&](bf16x8 (&dst)[NB], int s) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int r = 16 * b + c;
+        dst[b] = *(const bf16x8*)(xb + r * (KC * 2) + (((4 * s + q) ^ (r & 15)) << 4));
+      }
+    };
+    read_x(xf[0], 0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (s < nks) {
+        if (s + 1 < KS && s + 1 < nks) read_x(xf[(s + 1) & 1], s + 1);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const int r = 16 * b + c;
-          const bf16x8 xf = *(const bf16x8*)(xb + r * (KC * 2) + (((4 * s + q) ^ (r & 15)) << 4));
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int t = 0; t < NT; ++t)
-            acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[t][s], xf, acc[t][b], 0, 0, 0);
-        }
+            acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[t][s], xf[s & 1][b], acc[t][b], 0, 0, 0);
       }
     }
   };
@@ -422,7 +430,7 @@ extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias,
                                  int K, int ldx, int ldw, int ldo, int epi, int splitk, int w_tiled,
                                  hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
-  if (Bsz <= 0 || Bsz > 128 || N <= 0 || K <= 0 || (K % 32) || (N % 16) || (epi == EPI_SWIGLU && (N % 32)) || (ldx % 8) || (ldw % 8) || (ldo % 4) ||
+  if (Bsz <= 0 || Bsz > 256 || N <= 0 || K <= 0 || (K % 32) || (N % 16) || (epi == EPI_SWIGLU && (N % 32)) || (ldx % 8) || (ldw % 8) || (ldo % 4) ||
       splitk < 1)
     return HWOCR_EINVAL;
   if (epi != EPI_PARTIAL && splitk != 1) return HWOCR_EINVAL;
@@ -439,6 +447,8 @@ extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias,
     case 3: return launch_skinny<3>(a, epi, splitk, w_tiled != 0, stream);
     case 4: return launch_skinny<4>(a, epi, splitk, w_tiled != 0, stream);
     case 5: case 6: return launch_skinny<6>(a, epi, splitk, w_tiled != 0, stream);
-    default: return launch_skinny<8>(a, epi, splitk, w_tiled != 0, stream);
+    case 7: case 8: return launch_skinny<8>(a, epi, splitk, w_tiled != 0, stream);
+    case 9: case 10: case 11: case 12: return launch_skinny<12>(a, epi, splitk, w_tiled != 0, stream);
+    default: return launch_skinny<16>(a, epi, splitk, w_tiled != 0, stream);
   }
 }

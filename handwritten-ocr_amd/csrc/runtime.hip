@@ -129,7 +129,7 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
 
 extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
                                  const hwocr_gen_state* gs, int nseq, int attn_splits, hipStream_t st) {
-  if (!m || !ws || !kv || !gs || nseq <= 0 || nseq > 128 || nseq > kv->nseq_max || attn_splits < 1)
+  if (!m || !ws || !kv || !gs || nseq <= 0 || nseq > 256 || nseq > kv->nseq_max || attn_splits < 1)
     return HWOCR_EINVAL;
   const int Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
   const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;

@@ -200,8 +200,8 @@ class ReadEngine:
         cfg.validate()
         if not torch.cuda.is_available():
             raise _lib.HwocrError("ReadEngine needs an MI355X (ROCm) device: there is no CPU path")
-        if max_reads < 1 or max_reads > 128:
-            raise ValueError("max_reads must be in 1..128 (one decode batch)")
+        if max_reads < 1 or max_reads > 256:
+            raise ValueError("max_reads must be in 1..256 (one decode batch)")
         self.cfg = cfg
         self.dev = torch.device(device)
         torch.cuda.set_device(self.dev)
@@ -500,7 +500,7 @@ class ReadEngine:
             step_logits.append(torch.cat(first_logits, dim=0))
         if forced is not None:
             self.cur_ids[:R].copy_(torch.from_numpy(np.ascontiguousarray(forced[:, 0]).astype(np.int32)).to(dev))
-        splits = self.attn_splits or max(1, min(16, 768 // max(1, R * c.kv_heads)))
+        splits = self.attn_splits or (1 if R * c.kv_heads >= 160 else max(2, min(16, 768 // max(1, R * c.kv_heads))))
         steps = max_new - 1
         if use_graph and not return_logits and forced is None and steps > 0:
             key = (R, splits, max_new, min_new)

@@ -47,7 +47,7 @@ const char* hwocr_last_error(void);
 int hwocr_gemm_wide(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
                     int ldx, int ldw, int ldo, int ldres, int epi, hwocr_stream_t stream);
 
-/* Same contraction for <= 128 rows (decode).  epi PARTIAL writes fp32 slabs out[splitk][Bsz][ldo].
+/* Same contraction for <= 256 rows (decode).  epi PARTIAL writes fp32 slabs out[splitk][Bsz][ldo].
  * w_tiled != 0: W is the fragment-tiled copy made by hwocr_tile_weights (ldw ignored). */
 int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out, int Bsz, int N, int K, int ldx,
                       int ldw, int ldo, int epi, int splitk, int w_tiled, hwocr_stream_t stream);

@@ -95,7 +95,7 @@ def test_tile_weights_layout():
 
 
 @pytest.mark.parametrize("tiled", [0, 1])
-@pytest.mark.parametrize("B", [1, 7, 16, 48, 96, 128])
+@pytest.mark.parametrize("B", [1, 7, 16, 48, 96, 128, 190, 256])
 @pytest.mark.parametrize("N,K", [(96, 64), (2048, 1536), (1536, 2304)])
 def test_gemm_skinny_linear_and_partial(B, N, K, tiled):
     x = randbf(B, K, seed=7)
@@ -120,7 +120,7 @@ def test_gemm_skinny_linear_and_partial(B, N, K, tiled):
 
 
 @pytest.mark.parametrize("tiled", [0, 1])
-@pytest.mark.parametrize("B", [3, 48, 96])
+@pytest.mark.parametrize("B", [3, 48, 96, 252])
 def test_gemm_skinny_swiglu(B, tiled):
     N, K = 2 * 1792, 1536
     x = randbf(B, K, seed=10)
