@@ -80,7 +80,13 @@ def cpu_baseline(cfg, side: int, n_out: int, reads_per_page: int) -> dict:
     from oracle import image_ref, text_ref
     from oracle.qwen2vl_ref import Qwen2VLRef, RefConfig
 
-    threads = torch.get_num_threads()
+    # the GPU box grants ~16 host cores per GPU; more torch threads than that only oversubscribe
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(torch.get_num_threads(), avail, 16))
+    torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
 
     def rn(*shape):
