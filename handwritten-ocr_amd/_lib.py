@@ -33,14 +33,20 @@ def check(rc: int, what: str = "") -> None:
 
 class VitBlock(C.Structure):
     _fields_ = [(n, P) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_w", "ln2_b",
-                                  "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+                                  "fc1_w", "fc1_b", "fc2_w", "fc2_b")] + [("windowed", I)]
 
 
 class Vit(C.Structure):
-    _fields_ = [(n, I) for n in ("depth", "dim", "heads", "mlp_dim", "patch", "merge", "tps", "kpad", "out_dim")] + [
+    _fields_ = [(n, I) for n in ("depth", "dim", "heads", "mlp_dim", "patch", "merge", "tps", "kpad", "out_dim",
+                                 "kind")] + [
         ("eps", F), ("patch_w", P), ("blocks", C.POINTER(VitBlock)),
         ("merger_ln_w", P), ("merger_ln_b", P), ("merger_fc1_w", P), ("merger_fc1_b", P),
         ("merger_fc2_w", P), ("merger_fc2_b", P), ("rope_cos", P), ("rope_sin", P), ("pixel_lut", P)]
+
+
+class VitLayout(C.Structure):
+    _fields_ = [(n, P) for n in ("pos_h", "pos_w", "seg_lens", "row_src", "win_off", "win_lens")] + [
+        ("nwin", I), ("max_win", I)]
 
 
 class VitWs(C.Structure):
@@ -79,7 +85,8 @@ _HIP_SIGS = {
     "hwocr_tile_weights": ([P, P, I, I, I, P], I),
     "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, I, P], I),
     "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, P], I),
-    "hwocr_patchify": ([P, P, P, I, I, I, I, I, I, I, I, P], I),
+    "hwocr_attn_varlen": ([P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, F, P], I),
+    "hwocr_patchify": ([P, P, P, I, I, I, I, I, I, I, I, P, P], I),
     "hwocr_layernorm": ([P, P, P, P, I, I, I, I, F, P], I),
     "hwocr_add_rmsnorm": ([P, I, L, I, P, P, I, P, P, I, P, I, I, F, I, P], I),
     "hwocr_vit_rope_split": ([P, P, P, P, P, P, P, P, I, I, I, I, P], I),
@@ -87,7 +94,7 @@ _HIP_SIGS = {
     "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, I, P], I),
     "hwocr_embed_splice": ([P, P, P, P, P, I, I, F, P], I),
     "hwocr_argmax_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P], I),
-    "hwocr_vit_forward": ([C.POINTER(Vit), C.POINTER(VitWs), P, I, I, I, I, P, P, P, P, P], I),
+    "hwocr_vit_forward": ([C.POINTER(Vit), C.POINTER(VitWs), P, I, I, I, I, C.POINTER(VitLayout), P, P], I),
     "hwocr_prefill": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), P, P, P, P, P, P,
                        I, I, I, I, P], I),
     "hwocr_decode_step": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), I, I, P], I),

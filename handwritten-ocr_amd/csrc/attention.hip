@@ -29,6 +29,7 @@ struct PrefillArgs {
   float scale_log2;   // softmax scale * log2(e)
   int kv_tiled;       // K / V^T in the fragment-tiled cache layout (common.cuh) instead of rows
   int heads, nseg, qblocks;  // 1-D grid decomposition (attn_vit80_kernel)
+  const int* seg_off;        // packed ragged segments (hwocr_attn_varlen): first row of every segment, multiple of 4
 };
 
 __device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
@@ -52,9 +53,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int hk = h / a.group;
-  const bf16* Qp = a.Q + seg * a.q_seg + h * a.q_head;
-  const bf16* Kp = a.K + seg * a.k_seg + hk * a.k_head;
-  const bf16* Vp = a.VT + seg * a.v_seg + hk * a.v_head;
+  const long off = a.seg_off ? a.seg_off[seg] : 0;  // varlen: rows of all segments share one packed buffer
+  const bf16* Qp = a.Q + seg * a.q_seg + h * a.q_head + off * a.q_row;
+  const bf16* Kp = a.K + seg * a.k_seg + hk * a.k_head + off * a.k_row;
+  const bf16* Vp = a.VT + seg * a.v_seg + hk * a.v_head + off;
 
   const int qi = q0 + 32 * w + r;  // this lane's query column
   const int rk = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);  // r with bits 2 and 3 swapped
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
       const int id = tid + 256 * i;
       if (id < CV) {
         const int d = id >> 3, ch = id & 7;
-        bf16x8 v = *(const bf16x8*)(Vp + (a.kv_tiled ? kv_tiled_v(d, j0 + ch * 8) : (long)d * a.v_row + j0 + ch * 8));
+        const bf16* vp = Vp + (a.kv_tiled ? kv_tiled_v(d, j0 + ch * 8) : (long)d * a.v_row + j0 + ch * 8);
+        // a ragged segment starts on a 4-key (8-byte) boundary only
+        bf16x8 v = a.seg_off ? cat4(*(const bf16x4*)vp, *(const bf16x4*)(vp + 4)) : *(const bf16x8*)vp;
         if (j0 + 64 > len) {  // tail tile: keys past the segment carry p = 0, keep 0 * x finite
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
   l += __shfl_xor(l, 32);
   const float inv = 1.0f / l;
   if (qi < len) {
-    bf16* orow = a.O + seg * a.o_seg + (long)qi * a.o_row + h * HD;
+    bf16* orow = a.O + seg * a.o_seg + (off + qi) * a.o_row + h * HD;
 #pragma unroll
     for (int d = 0; d < ND; ++d)
 #pragma unroll
@@ -640,6 +644,26 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
                                     : launch_prefill<64, false>(a, nseg, heads, max_len, stream);
   if (head_dim == 32) return causal ? launch_prefill<32, true>(a, nseg, heads, max_len, stream)
                                     : launch_prefill<32, false>(a, nseg, heads, max_len, stream);
+  return HWOCR_EINVAL;
+}
+
+extern "C" int hwocr_attn_varlen(const void* Q, const void* K, const void* VT, void* O, const int* seg_off,
+                                 const int* lens, int nseg, int heads, int head_dim, int max_len, long q_head,
+                                 long q_row, long k_head, long k_row, long v_head, long v_row, long o_row, float scale,
+                                 hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
+  if (!seg_off || !lens || nseg <= 0 || heads <= 0 || max_len <= 0) return HWOCR_EINVAL;
+  if ((q_row % 8) || (k_row % 8) || (v_row % 8) || (o_row % 4) || (q_head % 8) || (k_head % 8) || (v_head % 8))
+    return HWOCR_EINVAL;
+  PrefillArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, (bf16*)O, lens,
+                0, q_head, q_row, 0, k_head, k_row, 0, v_head, v_row, 0, o_row,
+                1, scale * 1.4426950408889634f, 0, heads, nseg, (max_len + 127) / 128, seg_off};
+  switch (head_dim) {
+    case 32: return launch_prefill<32, false>(a, nseg, heads, max_len, stream);
+    case 64: return launch_prefill<64, false>(a, nseg, heads, max_len, stream);
+    case 80: return launch_prefill<80, false>(a, nseg, heads, max_len, stream);
+    case 128: return launch_prefill<128, false>(a, nseg, heads, max_len, stream);
+  }
   return HWOCR_EINVAL;
 }
 

@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int MAXC = 4;  // 16-byte chunks per lane per row -> row width <= 64*8*4 = 2048
+constexpr int MAXC = 8;  // 16-byte chunks per lane per row -> row width <= 64*8*8 = 4096
 
 // ------------------------------------------------------------------------------------------------
 // patchify: resized uint8 page -> bf16 patch rows.  Replaces rescale + normalize + patchify of
@@ -17,7 +17,7 @@ constexpr int MAXC = 4;  // 16-byte chunks per lane per row -> row width <= 64*8
 // Row order: (gh/m, gw/m, m, m); column order: (C, T, ph, pw), T = temporal duplicate.
 // ------------------------------------------------------------------------------------------------
 struct PatchifyArgs {
-  const uint8_t* img; const bf16* lut; bf16* out;
+  const uint8_t* img; const bf16* lut; bf16* out; const int* row_src;
   int nimg, H, W, gh, gw, patch, merge, tps, kreal, kpad, img_ld;
 };
 __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a) {
@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a) {
   const int P = a.gh * a.gw;
   const int im = row / P, p = row % P;
   const int mm = a.merge * a.merge;
-  const int blk = p / mm, within = p % mm;
+  const int ps = a.row_src ? a.row_src[p] : p;  // output row p shows source patch ps (window order, Qwen2.5-VL)
+  const int blk = ps / mm, within = ps % mm;
   const int bw_n = a.gw / a.merge;
   const int pr = (blk / bw_n) * a.merge + within / a.merge;
   const int pc = (blk % bw_n) * a.merge + within % a.merge;
@@ -164,10 +165,12 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(RmsArgs a) {
   }
 }
 
-// Few rows (decode: one row per read): one 256-thread workgroup per row, every thread owns <= 1 chunk of 8 elements,
-// all slab loads of a thread are independent and in flight together; the row statistic goes through LDS.
-__global__ __launch_bounds__(256) void add_rmsnorm_row_kernel(RmsArgs a) {
-  __shared__ float s_part[4];
+// Few rows (decode: one row per read): one workgroup of NT threads per row (256: D <= 2048, 512: D <= 4096), every
+// thread owns <= 1 chunk of 8 elements, all slab loads of a thread are independent and in flight together; the row
+// statistic goes through LDS.
+template <int NT>
+__global__ __launch_bounds__(NT) void add_rmsnorm_row_kernel(RmsArgs a) {
+  __shared__ float s_part[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int row = blockIdx.x;
   const int src = a.row_index ? a.row_index[row] : row;
@@ -220,7 +223,10 @@ __global__ __launch_bounds__(256) void add_rmsnorm_row_kernel(RmsArgs a) {
   ss = wave_sum(ss);
   if (lane == 0) s_part[w] = ss;
   __syncthreads();
-  const float rstd = rsqrtf((s_part[0] + s_part[1] + s_part[2] + s_part[3]) / a.D + a.eps);
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) tot += s_part[i];
+  const float rstd = rsqrtf(tot / a.D + a.eps);
   if (live) {
     const bf16x8 g = *(const bf16x8*)(a.w + tid * 8);
     bf16x8 o;
@@ -508,12 +514,13 @@ __global__ __launch_bounds__(256) void argmax_advance_kernel(SelectArgs a) {
 }  // namespace
 
 extern "C" int hwocr_patchify(const void* img, const void* lut, void* out, int nimg, int H, int W, int patch,
-                              int merge, int tps, int kpad, int rows_per_img_ld, hipStream_t stream) {
+                              int merge, int tps, int kpad, int rows_per_img_ld, const int* row_src,
+                              hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nimg <= 0 || H % (patch * merge) || W % (patch * merge) || kpad % 8 || kpad < 3 * tps * patch * patch ||
       rows_per_img_ld < (H / patch) * (W / patch))
     return HWOCR_EINVAL;
-  PatchifyArgs a{(const uint8_t*)img, (const bf16*)lut, (bf16*)out, nimg, H, W, H / patch, W / patch,
+  PatchifyArgs a{(const uint8_t*)img, (const bf16*)lut, (bf16*)out, row_src, nimg, H, W, H / patch, W / patch,
                  patch, merge, tps, 3 * tps * patch * patch, kpad, rows_per_img_ld};
   const long total = (long)nimg * a.gh * a.gw * (kpad / 8);
   hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
@@ -539,7 +546,9 @@ extern "C" int hwocr_add_rmsnorm(const float* slabs, int nslab, long slab_stride
   RmsArgs a{slabs, nslab, slab_stride, ld_slab, (const bf16*)bias, (bf16*)h, ldh, (const bf16*)w, (bf16*)out, ldo,
             row_index, rows, D, eps, gemma};
   if (rows <= 512 && D <= 2048)
-    hipLaunchKernelGGL(add_rmsnorm_row_kernel, dim3(rows), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(add_rmsnorm_row_kernel<256>, dim3(rows), dim3(256), 0, stream, a);
+  else if (rows <= 512)
+    hipLaunchKernelGGL(add_rmsnorm_row_kernel<512>, dim3(rows), dim3(512), 0, stream, a);
   else
     hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
   return hwocr_launch_status();

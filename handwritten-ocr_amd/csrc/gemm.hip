@@ -361,7 +361,7 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 8) != 0 || (ldx % 8) || (ldw % 8) || (ldo % 4))
     return HWOCR_EINVAL;
-  if (epi == EPI_SWIGLU && ((N % 32) != 0 || bias)) return HWOCR_EINVAL;
+  if (epi == EPI_SWIGLU && (N % 32) != 0) return HWOCR_EINVAL;
   if (epi == EPI_RESIDUAL && (!res || (ldres % 4))) return HWOCR_EINVAL;
   WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)out,
              M, N, K, ldx, ldw, ldo, ldres, (M + BM - 1) / BM, (N + BN - 1) / BN};

@@ -64,9 +64,15 @@ __device__ __forceinline__ void store_tile(const WideArgs& a, const f32x4& acc, 
 // gate tile (weight rows n_gate .. +15) and the up tile that follows it -> out[m][n_gate/2 + 4q .. +3]
 __device__ __forceinline__ void store_swiglu(const WideArgs& a, const f32x4& g, const f32x4& u, int m, int n_gate, int q) {
   if (m >= a.M || n_gate >= a.N) return;
+  float gb[4] = {0.f, 0.f, 0.f, 0.f}, ub[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {  // bias rows follow the interleaved weight rows (Qwen2.5-VL vision MLP)
+    const bf16x4 bg = *(const bf16x4*)(a.bias + n_gate + 4 * q), bu = *(const bf16x4*)(a.bias + n_gate + 16 + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gb[r] = bf2f(bg[r]); ub[r] = bf2f(bu[r]); }
+  }
   bf16x4 o;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(act_silu(rbf(g[r]))) * rbf(u[r]));
+  for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(act_silu(rbf(g[r] + gb[r]))) * rbf(u[r] + ub[r]));
   *(bf16x4*)(a.out + (size_t)m * a.ldo + (n_gate >> 1) + 4 * q) = o;
 }
 

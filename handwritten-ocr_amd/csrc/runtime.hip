@@ -1,6 +1,7 @@
 // Model-level launch sequences: what `model.generate` (ocr_agent/tools.py:764-765) expands to for the
 // Qwen2-VL family, expressed as kernel launches on one HIP stream with caller-owned buffers.
-//   hwocr_vit_forward  <- Qwen2VisionTransformerPretrainedModel.forward (HF modeling_qwen2_vl.py:700-729)
+//   hwocr_vit_forward  <- Qwen2VisionTransformerPretrainedModel.forward (HF modeling_qwen2_vl.py:700-729) and
+//                         Qwen2_5_VisionTransformerPretrainedModel.forward (HF modeling_qwen2_5_vl.py:407-481)
 //   hwocr_prefill      <- Qwen2VLModel.forward splice + Qwen2VLTextModel.forward + lm_head (… :790-872, :1383-1387)
 //   hwocr_decode_step  <- one iteration of GenerationMixin._sample's while loop (HF generation/utils.py:2876-2941)
 // The decode step touches only device state (token ids, lengths, stop flags live in HBM), so it can be captured
@@ -33,7 +34,7 @@ inline int pick_splitk(int K, int N, int want_wgs) {
 }
 }  // namespace
 
-extern "C" int hwocr_abi_version(void) { return 1; }
+extern "C" int hwocr_abi_version(void) { return 2; }
 
 static char g_last_error[256] = "";
 extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text) {
@@ -42,38 +43,54 @@ extern "C" void hwocr_record_error(const char* where, int hip_error, const char*
 extern "C" const char* hwocr_last_error(void) { return g_last_error; }
 
 extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, const void* images, int nimg, int H,
-                                 int W, int rows_per_img_ld, const int* pos_h, const int* pos_w,
-                                 const int* seg_lens, void* out, hipStream_t st) {
-  if (!m || !ws || nimg <= 0 || rows_per_img_ld % 64) return HWOCR_EINVAL;
+                                 int W, int rows_per_img_ld, const hwocr_vit_layout* lay, void* out, hipStream_t st) {
+  if (!m || !ws || !lay || nimg <= 0 || rows_per_img_ld % 64) return HWOCR_EINVAL;
   const int D = m->dim, hd = D / m->heads, rows = nimg * rows_per_img_ld;
   const int P = (H / m->patch) * (W / m->patch);
   const int mm = m->merge * m->merge;
+  const bool v25 = m->kind == HWOCR_VIT_QWEN2_5;
+  // pre-attention / pre-MLP / merger norm of the family
+  auto norm = [&](const void* w, const void* b) {
+    return v25 ? hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->x, D, w, ws->xn, D, nullptr, rows, D, m->eps, 0, st)
+               : hwocr_layernorm(ws->x, w, b, ws->xn, rows, D, D, D, m->eps, st);
+  };
   CHECK(hwocr_patchify(images, m->pixel_lut, ws->patches, nimg, H, W, m->patch, m->merge, m->tps, m->kpad,
-                       rows_per_img_ld, st));
+                       rows_per_img_ld, lay->row_src, st));
   CHECK(hwocr_gemm_wide(ws->patches, m->patch_w, nullptr, nullptr, ws->x, rows, D, m->kpad, m->kpad, m->kpad, D, 0,
                         HWOCR_EPI_LINEAR, st));
   const float scale = 1.0f / sqrtf((float)hd);
   for (int l = 0; l < m->depth; ++l) {
     const hwocr_vit_block& b = m->blocks[l];
-    CHECK(hwocr_layernorm(ws->x, b.ln1_w, b.ln1_b, ws->xn, rows, D, D, D, m->eps, st));
+    CHECK(norm(b.ln1_w, b.ln1_b));
     CHECK(hwocr_gemm_wide(ws->xn, b.qkv_w, b.qkv_b, nullptr, ws->qkv, rows, 3 * D, D, D, D, 3 * D, 0,
                           HWOCR_EPI_LINEAR, st));
-    CHECK(hwocr_vit_rope_split(ws->qkv, ws->q, ws->k, ws->vt, pos_h, pos_w, m->rope_cos, m->rope_sin, rows, rows,
-                               m->heads, hd, st));
-    CHECK(hwocr_attn_prefill(ws->q, ws->k, ws->vt, ws->attn, seg_lens, nimg, m->heads, 1, hd, P, 0,
-                             (long)rows_per_img_ld * hd, (long)rows * hd, hd,   // Q [head][rows][hd]
-                             (long)rows_per_img_ld * hd, (long)rows * hd, hd,   // K
-                             rows_per_img_ld, (long)hd * rows, rows,            // V^T [head][hd][rows]
-                             (long)rows_per_img_ld * D, D, scale, 0, st));
+    CHECK(hwocr_vit_rope_split(ws->qkv, ws->q, ws->k, ws->vt, lay->pos_h, lay->pos_w, m->rope_cos, m->rope_sin, rows,
+                               rows, m->heads, hd, st));
+    if (v25 && b.windowed && lay->nwin > 0) {
+      CHECK(hwocr_attn_varlen(ws->q, ws->k, ws->vt, ws->attn, lay->win_off, lay->win_lens, lay->nwin, m->heads, hd,
+                              lay->max_win, (long)rows * hd, hd, (long)rows * hd, hd, (long)hd * rows, rows, D, scale,
+                              st));
+    } else {
+      CHECK(hwocr_attn_prefill(ws->q, ws->k, ws->vt, ws->attn, lay->seg_lens, nimg, m->heads, 1, hd, P, 0,
+                               (long)rows_per_img_ld * hd, (long)rows * hd, hd,   // Q [head][rows][hd]
+                               (long)rows_per_img_ld * hd, (long)rows * hd, hd,   // K
+                               rows_per_img_ld, (long)hd * rows, rows,            // V^T [head][hd][rows]
+                               (long)rows_per_img_ld * D, D, scale, 0, st));
+    }
     CHECK(hwocr_gemm_wide(ws->attn, b.proj_w, b.proj_b, ws->x, ws->x, rows, D, D, D, D, D, D, HWOCR_EPI_RESIDUAL, st));
-    CHECK(hwocr_layernorm(ws->x, b.ln2_w, b.ln2_b, ws->xn, rows, D, D, D, m->eps, st));
-    CHECK(hwocr_gemm_wide(ws->xn, b.fc1_w, b.fc1_b, nullptr, ws->mlp, rows, m->mlp_dim, D, D, D, m->mlp_dim, 0,
-                          HWOCR_EPI_QUICKGELU, st));
+    CHECK(norm(b.ln2_w, b.ln2_b));
+    if (v25) {  // down(silu(gate(x)) * up(x)), all three with bias (HF modeling_qwen2_5_vl.py:84-96)
+      CHECK(hwocr_gemm_wide(ws->xn, b.fc1_w, b.fc1_b, nullptr, ws->mlp, rows, 2 * m->mlp_dim, D, D, D, m->mlp_dim, 0,
+                            HWOCR_EPI_SWIGLU, st));
+    } else {
+      CHECK(hwocr_gemm_wide(ws->xn, b.fc1_w, b.fc1_b, nullptr, ws->mlp, rows, m->mlp_dim, D, D, D, m->mlp_dim, 0,
+                            HWOCR_EPI_QUICKGELU, st));
+    }
     CHECK(hwocr_gemm_wide(ws->mlp, b.fc2_w, b.fc2_b, ws->x, ws->x, rows, D, m->mlp_dim, m->mlp_dim, m->mlp_dim, D, D,
                           HWOCR_EPI_RESIDUAL, st));
   }
-  // patch merger: LN -> view(-1, merge^2 * D) -> Linear -> GELU -> Linear
-  CHECK(hwocr_layernorm(ws->x, m->merger_ln_w, m->merger_ln_b, ws->xn, rows, D, D, D, m->eps, st));
+  // patch merger: norm -> view(-1, merge^2 * D) -> Linear -> GELU -> Linear
+  CHECK(norm(m->merger_ln_w, m->merger_ln_b));
   const int mrows = rows / mm, MD = mm * D;
   CHECK(hwocr_gemm_wide(ws->xn, m->merger_fc1_w, m->merger_fc1_b, nullptr, ws->merge_mid, mrows, MD, MD, MD, MD, MD, 0,
                         HWOCR_EPI_GELU, st));

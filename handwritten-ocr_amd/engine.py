@@ -1,5 +1,6 @@
 """Read engine: the MI355X-native replacement for `model.generate` on the reference's OCR path
-(ocr_agent/tools.py:764-765) for the Qwen2-VL family.
+(ocr_agent/tools.py:764-765) for the Qwen2-VL family and the Qwen2.5-VL family (olmOCR-2, the reference's default
+OCR_MODEL, ocr_agent/config.py:15).
 
 Python here is plumbing only — shapes, index tables, buffer ownership (torch-ROCm tensors) and three calls into
 libhwocr_hip.so per batch of reads:
@@ -40,6 +41,11 @@ class ModelConfig:
     patch_size: int = 14
     merge: int = 2
     tps: int = 2
+    # Qwen2.5-VL tower only (family "qwen2_5_vl"): gated MLP width, attention window (pixels), full-attention layers
+    family: str = "qwen2_vl"
+    vit_inter: int = 0
+    window_size: int = 112
+    fullatt: tuple = (7, 15, 23, 31)
     # decoder
     hidden: int = 1536
     layers: int = 28
@@ -69,6 +75,9 @@ class ModelConfig:
 
     @property
     def mlp_dim(self) -> int:
+        """Width of the tower's MLP activation buffer; the Qwen2.5-VL intermediate size (3420) is zero-padded to x64."""
+        if self.family == "qwen2_5_vl":
+            return (self.vit_inter + 63) // 64 * 64
         return int(self.embed_dim * self.mlp_ratio)
 
     @property
@@ -88,12 +97,29 @@ class ModelConfig:
             raise ValueError("widths must be multiples of 64 (vocab: 32)")
         if sum(self.mrope_section) * 2 != HD:
             raise ValueError("mrope_section must sum to head_dim/2")
+        if self.family not in ("qwen2_vl", "qwen2_5_vl"):
+            raise ValueError(f"unknown model family {self.family!r}")
+        if self.family == "qwen2_5_vl" and (self.vit_inter <= 0 or self.window_size < self.merge * self.patch_size):
+            raise ValueError("qwen2_5_vl needs vit_inter and a window of at least one merged token")
+        if self.hidden > 4096 or self.embed_dim > 4096:
+            raise ValueError("norm kernels are built for rows of at most 4096 elements")
 
 
 def preset(name: str) -> ModelConfig:
     """Shapes of BASELINE.json's configs (public model-card values)."""
     if name in ("qwen2-vl-2b", "Qwen/Qwen2-VL-2B-Instruct"):
         return ModelConfig()
+    if name in ("qwen2.5-vl-7b", "olmocr-2-7b", "allenai/olmOCR-2-7B-1025", "Qwen/Qwen2.5-VL-7B-Instruct"):
+        return ModelConfig(name="qwen2.5-vl-7b", family="qwen2_5_vl", vit_inter=3420, hidden=3584, layers=28, q_heads=28,
+                           kv_heads=4, inter=18944, vocab=152064, tie=False)
+    if name in ("qwen2.5-vl-3b", "Qwen/Qwen2.5-VL-3B-Instruct"):
+        return ModelConfig(name="qwen2.5-vl-3b", family="qwen2_5_vl", vit_inter=3420, hidden=2048, layers=36, q_heads=16,
+                           kv_heads=2, inter=11008, vocab=151936, tie=True)
+    if name == "tiny25":  # tests/golden/qwen25vl_tiny.json
+        return ModelConfig(name="tiny25", family="qwen2_5_vl", depth=3, embed_dim=64, num_heads=2, vit_inter=88, window_size=56,
+                           fullatt=(1,), hidden=256, layers=2, q_heads=2, kv_heads=1, inter=256, vocab=512, image_token_id=500,
+                           vision_start_id=502, vision_end_id=503, im_start_id=504, im_end_id=505, eos_ids=(510,), pad_id=511,
+                           min_pixels=28 * 28)
     if name == "tiny":  # tests/golden/qwen2vl_tiny.json
         return ModelConfig(name="tiny", depth=2, embed_dim=64, num_heads=2, mlp_ratio=2, hidden=256, layers=2, q_heads=2,
                            kv_heads=1, inter=256, vocab=512, image_token_id=500, vision_start_id=502, vision_end_id=503,
@@ -119,16 +145,25 @@ def random_state_dict(cfg: ModelConfig, seed: int = 0, device="cuda", std: float
     D, H = cfg.embed_dim, cfg.hidden
     v = "model.visual."
     sd[v + "patch_embed.proj.weight"] = rn(D, 3, cfg.tps, cfg.patch_size, cfg.patch_size)
+    v25 = cfg.family == "qwen2_5_vl"
     for l in range(cfg.depth):
         b = f"{v}blocks.{l}."
-        sd[b + "norm1.weight"], sd[b + "norm1.bias"] = ones_ish(D), rn(D)
-        sd[b + "norm2.weight"], sd[b + "norm2.bias"] = ones_ish(D), rn(D)
+        sd[b + "norm1.weight"], sd[b + "norm2.weight"] = ones_ish(D), ones_ish(D)
         sd[b + "attn.qkv.weight"], sd[b + "attn.qkv.bias"] = rn(3 * D, D), rn(3 * D)
         sd[b + "attn.proj.weight"], sd[b + "attn.proj.bias"] = rn(D, D), rn(D)
-        sd[b + "mlp.fc1.weight"], sd[b + "mlp.fc1.bias"] = rn(cfg.mlp_dim, D), rn(cfg.mlp_dim)
-        sd[b + "mlp.fc2.weight"], sd[b + "mlp.fc2.bias"] = rn(D, cfg.mlp_dim), rn(D)
+        if v25:
+            I = cfg.vit_inter
+            sd[b + "mlp.gate_proj.weight"], sd[b + "mlp.gate_proj.bias"] = rn(I, D), rn(I)
+            sd[b + "mlp.up_proj.weight"], sd[b + "mlp.up_proj.bias"] = rn(I, D), rn(I)
+            sd[b + "mlp.down_proj.weight"], sd[b + "mlp.down_proj.bias"] = rn(D, I), rn(D)
+        else:
+            sd[b + "norm1.bias"], sd[b + "norm2.bias"] = rn(D), rn(D)
+            sd[b + "mlp.fc1.weight"], sd[b + "mlp.fc1.bias"] = rn(cfg.mlp_dim, D), rn(cfg.mlp_dim)
+            sd[b + "mlp.fc2.weight"], sd[b + "mlp.fc2.bias"] = rn(D, cfg.mlp_dim), rn(D)
     MD = D * cfg.merge ** 2
-    sd[v + "merger.ln_q.weight"], sd[v + "merger.ln_q.bias"] = ones_ish(D), rn(D)
+    sd[v + "merger.ln_q.weight"] = ones_ish(D)
+    if not v25:
+        sd[v + "merger.ln_q.bias"] = rn(D)
     sd[v + "merger.mlp.0.weight"], sd[v + "merger.mlp.0.bias"] = rn(MD, MD), rn(MD)
     sd[v + "merger.mlp.2.weight"], sd[v + "merger.mlp.2.bias"] = rn(H, MD), rn(H)
     t = "model.language_model."
@@ -164,7 +199,8 @@ def normalize_keys(sd: dict) -> dict:
 
 
 def load_checkpoint_dir(path: str, device="cuda") -> tuple[ModelConfig, dict]:
-    """Load config.json + *.safetensors of a Qwen2-VL checkpoint directory (safetensors only; nothing is unpickled)."""
+    """Load config.json + *.safetensors of a Qwen2-VL / Qwen2.5-VL (olmOCR-2) checkpoint directory (safetensors only;
+    nothing is unpickled)."""
     from safetensors.torch import load_file
 
     with open(os.path.join(path, "config.json")) as f:
@@ -172,9 +208,13 @@ def load_checkpoint_dir(path: str, device="cuda") -> tuple[ModelConfig, dict]:
     vc = hf.get("vision_config", {})
     tc = hf.get("text_config", hf)
     rope = tc.get("rope_parameters") or tc.get("rope_scaling") or {}
+    v25 = hf.get("model_type") == "qwen2_5_vl" or vc.get("model_type") == "qwen2_5_vl_vision" or "fullatt_block_indexes" in vc
+    tower = dict(family="qwen2_5_vl", embed_dim=vc.get("hidden_size", 1280), vit_inter=vc.get("intermediate_size", 3420),
+                 window_size=vc.get("window_size", 112), fullatt=tuple(vc.get("fullatt_block_indexes", (7, 15, 23, 31)))) \
+        if v25 else dict(embed_dim=vc.get("embed_dim", 1280), mlp_ratio=vc.get("mlp_ratio", 4))
     cfg = ModelConfig(
-        name=os.path.basename(path.rstrip("/")), depth=vc.get("depth", 32), embed_dim=vc.get("embed_dim", 1280),
-        num_heads=vc.get("num_heads", 16), mlp_ratio=vc.get("mlp_ratio", 4), patch_size=vc.get("patch_size", 14),
+        name=os.path.basename(path.rstrip("/")), depth=vc.get("depth", 32), **tower,
+        num_heads=vc.get("num_heads", 16), patch_size=vc.get("patch_size", 14),
         merge=vc.get("spatial_merge_size", 2), tps=vc.get("temporal_patch_size", 2), hidden=tc["hidden_size"],
         layers=tc["num_hidden_layers"], q_heads=tc["num_attention_heads"], kv_heads=tc["num_key_value_heads"],
         inter=tc["intermediate_size"], vocab=tc["vocab_size"], rope_theta=rope.get("rope_theta", tc.get("rope_theta", 1e6)),
@@ -242,13 +282,38 @@ class ReadEngine:
         pw[:, : c.patch_k] = sd[v + "patch_embed.proj.weight"].reshape(D, -1).to(self.dev, torch.bfloat16)
         self._keep.append(pw)
         blocks = (_lib.VitBlock * c.depth)()
+        v25 = c.family == "qwen2_5_vl"
         for l in range(c.depth):
             b = f"{v}blocks.{l}."
-            for fld, key in (("ln1_w", "norm1.weight"), ("ln1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
-                             ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
-                             ("ln2_w", "norm2.weight"), ("ln2_b", "norm2.bias"), ("fc1_w", "mlp.fc1.weight"),
-                             ("fc1_b", "mlp.fc1.bias"), ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias")):
+            common = (("ln1_w", "norm1.weight"), ("qkv_w", "attn.qkv.weight"), ("qkv_b", "attn.qkv.bias"),
+                      ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"), ("ln2_w", "norm2.weight"))
+            v2 = (("ln1_b", "norm1.bias"), ("ln2_b", "norm2.bias"), ("fc1_w", "mlp.fc1.weight"), ("fc1_b", "mlp.fc1.bias"),
+                  ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias"))
+            for fld, key in common + (() if v25 else v2):
                 setattr(blocks[l], fld, P(self._t(sd[b + key])))
+            if v25:
+                # gate/up (+ biases) zero-padded to mlp_dim rows and interleaved in 16-row tiles for the SwiGLU epilogue;
+                # padded rows give silu(0) * 0 = 0 and meet zero columns of down_proj
+                I, Ip = c.vit_inter, c.mlp_dim
+
+                def padrows(t):
+                    t = t.to(self.dev, torch.bfloat16)
+                    out = torch.zeros((Ip,) + tuple(t.shape[1:]), dtype=torch.bfloat16, device=self.dev)
+                    out[:I] = t
+                    return out
+
+                def interleave(g, u):
+                    g, u = padrows(g), padrows(u)
+                    tail = tuple(g.shape[1:])
+                    return torch.stack([g.reshape((Ip // 16, 16) + tail), u.reshape((Ip // 16, 16) + tail)], dim=1) \
+                        .reshape((2 * Ip,) + tail)
+
+                down = torch.zeros(D, Ip, dtype=torch.bfloat16, device=self.dev)
+                down[:, :I] = sd[b + "mlp.down_proj.weight"].to(self.dev, torch.bfloat16)
+                blocks[l].fc1_w = P(self._t(interleave(sd[b + "mlp.gate_proj.weight"], sd[b + "mlp.up_proj.weight"])))
+                blocks[l].fc1_b = P(self._t(interleave(sd[b + "mlp.gate_proj.bias"], sd[b + "mlp.up_proj.bias"])))
+                blocks[l].fc2_w, blocks[l].fc2_b = P(self._t(down)), P(self._t(sd[b + "mlp.down_proj.bias"]))
+                blocks[l].windowed = 0 if l in c.fullatt else 1
         # vision rotary table, fp32, exactly as the library builds it (positions * inv_freq, then cos/sin)
         hd = c.vit_hd
         inv = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float) / (hd // 2)))
@@ -257,8 +322,9 @@ class ReadEngine:
         self.vit_sin = ang.sin().contiguous().to(self.dev)
         self.lut = torch.from_numpy(imageproc.pixel_lut()).to(torch.bfloat16).to(self.dev)
         self.vit = _lib.Vit(depth=c.depth, dim=D, heads=c.num_heads, mlp_dim=c.mlp_dim, patch=c.patch_size, merge=c.merge,
-                            tps=c.tps, kpad=c.kpad, out_dim=c.hidden, eps=1e-6, patch_w=P(pw), blocks=blocks,
-                            merger_ln_w=P(self._t(sd[v + "merger.ln_q.weight"])), merger_ln_b=P(self._t(sd[v + "merger.ln_q.bias"])),
+                            tps=c.tps, kpad=c.kpad, out_dim=c.hidden, kind=1 if v25 else 0, eps=1e-6, patch_w=P(pw),
+                            blocks=blocks, merger_ln_w=P(self._t(sd[v + "merger.ln_q.weight"])),
+                            merger_ln_b=None if v25 else P(self._t(sd[v + "merger.ln_q.bias"])),
                             merger_fc1_w=P(self._t(sd[v + "merger.mlp.0.weight"])), merger_fc1_b=P(self._t(sd[v + "merger.mlp.0.bias"])),
                             merger_fc2_w=P(self._t(sd[v + "merger.mlp.2.weight"])), merger_fc2_b=P(self._t(sd[v + "merger.mlp.2.bias"])),
                             rope_cos=P(self.vit_cos), rope_sin=P(self.vit_sin), pixel_lut=P(self.lut))
@@ -351,7 +417,7 @@ class ReadEngine:
                 patches=torch.zeros(rows, c.kpad, dtype=bf, device=dev), x=torch.empty(rows, D, dtype=bf, device=dev),
                 xn=torch.empty(rows, D, dtype=bf, device=dev), qkv=torch.empty(rows, 3 * D, dtype=bf, device=dev),
                 q=torch.empty(rows * D, dtype=bf, device=dev), k=torch.empty(rows * D, dtype=bf, device=dev),
-                vt=torch.zeros(rows * D, dtype=bf, device=dev), attn=torch.empty(rows, D, dtype=bf, device=dev),
+                vt=torch.zeros(rows * D + 64, dtype=bf, device=dev), attn=torch.empty(rows, D, dtype=bf, device=dev),
                 mlp=torch.empty(rows, c.mlp_dim, dtype=bf, device=dev),
                 merge_mid=torch.empty(rows // mm, D * mm, dtype=bf, device=dev))
             self._vit_rows = rows
@@ -368,14 +434,17 @@ class ReadEngine:
         self._drop_graphs()
 
     # ------------------------------------------------------------------------------------------ vision tower
-    def encode_pages(self, pages: list[np.ndarray]) -> tuple[torch.Tensor, list[tuple[int, int, int]], list[int]]:
-        """uint8 [H, W, 3] pages already at tower resolution -> (embeddings [sum rows][hidden], grids, first row of
-        each page in the embedding buffer).  Pages of equal size are batched `vit_batch` at a time."""
+    def encode_pages(self, pages: list[np.ndarray]) -> tuple[torch.Tensor, list[tuple[int, int, int]], list[np.ndarray]]:
+        """uint8 [H, W, 3] pages already at tower resolution -> (embedding buffer [rows][hidden], grids, and for each
+        page the buffer row of every image token in prompt (raster) order).  Pages of equal size are batched
+        `vit_batch` at a time.  The Qwen2.5-VL tower works in window order from the patch gather on; its rows are never
+        moved back — the row table is the library's `merged[argsort(window_index)]` (HF modeling_qwen2_5_vl.py:474-476)."""
         c = self.cfg
         st = _lib.stream_handle()
         mm = c.merge ** 2
+        v25 = c.family == "qwen2_5_vl"
         grids = [(1, int(p.shape[0]) // c.patch_size, int(p.shape[1]) // c.patch_size) for p in pages]
-        first = [0] * len(pages)
+        tok_rows: list = [None] * len(pages)
         chunks = []
         total = 0
         by_shape: dict = {}
@@ -386,6 +455,13 @@ class ReadEngine:
             P = gh * gw
             Pp = _ceil(P, 64)
             ph, pw = imageproc.vision_positions(gh, gw, c.merge)
+            slot = np.arange(P // mm, dtype=np.int32)  # buffer slot (within the page) of merged token i
+            if v25:
+                order, win_lens = imageproc.window_order(gh, gw, c.merge, c.window_size, c.patch_size)
+                row_src = (order[:, None] * mm + np.arange(mm, dtype=np.int32)[None, :]).reshape(-1).astype(np.int32)
+                ph, pw = ph[row_src], pw[row_src]
+                slot = np.argsort(order).astype(np.int32)
+                win_start = np.concatenate([[0], np.cumsum(win_lens)[:-1]]).astype(np.int32)
             for s in range(0, len(idxs), self.vit_batch):
                 group = idxs[s: s + self.vit_batch]
                 n = len(group)
@@ -398,9 +474,17 @@ class ReadEngine:
                     wwp = np.zeros(rows, np.int32)
                     for j in range(n):
                         hh[j * Pp: j * Pp + P], wwp[j * Pp: j * Pp + P] = ph, pw
-                    self._pos_h = torch.from_numpy(hh).to(self.dev)
-                    self._pos_w = torch.from_numpy(wwp).to(self.dev)
-                    self._seg = torch.full((n,), P, dtype=torch.int32, device=self.dev)
+                    t = dict(pos_h=torch.from_numpy(hh).to(self.dev), pos_w=torch.from_numpy(wwp).to(self.dev),
+                             seg=torch.full((n,), P, dtype=torch.int32, device=self.dev))
+                    lay = _lib.VitLayout(pos_h=_lib.ptr(t["pos_h"]), pos_w=_lib.ptr(t["pos_w"]), seg_lens=_lib.ptr(t["seg"]))
+                    if v25:
+                        off = np.concatenate([win_start + j * Pp for j in range(n)]).astype(np.int32)
+                        t["row_src"] = torch.from_numpy(row_src).to(self.dev)
+                        t["win_off"] = torch.from_numpy(off).to(self.dev)
+                        t["win_lens"] = torch.from_numpy(np.tile(win_lens, n)).to(self.dev)
+                        lay.row_src, lay.win_off, lay.win_lens = (_lib.ptr(t[k]) for k in ("row_src", "win_off", "win_lens"))
+                        lay.nwin, lay.max_win = len(off), int(win_lens.max())
+                    self._vit_tables, self._vit_lay = t, lay
                     self._vbufs["patches"].zero_()
                     self._vit_layout = layout
                 if isinstance(pages[group[0]], torch.Tensor):  # already resident in HBM
@@ -409,15 +493,14 @@ class ReadEngine:
                     imgs = torch.from_numpy(np.stack([pages[i] for i in group])).to(self.dev, non_blocking=True)
                 out = torch.empty(rows // mm, c.hidden, dtype=torch.bfloat16, device=self.dev)
                 _lib.check(self.lib.hwocr_vit_forward(C.byref(self.vit), C.byref(ws), _lib.ptr(imgs), n, H, W, Pp,
-                                                      _lib.ptr(self._pos_h), _lib.ptr(self._pos_w), _lib.ptr(self._seg),
-                                                      _lib.ptr(out), st), "hwocr_vit_forward")
+                                                      C.byref(self._vit_lay), _lib.ptr(out), st), "hwocr_vit_forward")
                 self._keep_tmp = imgs
                 for j, i in enumerate(group):
-                    first[i] = total + j * (Pp // mm)
+                    tok_rows[i] = total + j * (Pp // mm) + slot
                 total += rows // mm
                 chunks.append(out)
         emb = chunks[0] if len(chunks) == 1 else torch.cat(chunks, dim=0)
-        return emb, grids, first
+        return emb, grids, tok_rows
 
     # ------------------------------------------------------------------------------------------ generate
     def generate(self, pages: list[np.ndarray], prompts: list[np.ndarray], max_new: int, min_new: int = 0,
@@ -441,7 +524,7 @@ class ReadEngine:
                 marks.append((name, ev))
 
         mark("start")
-        emb, grids, first = self.encode_pages(pages)
+        emb, grids, tok_rows = self.encode_pages(pages)
         mark("vision")
         T = [len(p) for p in prompts]
         Tp = _ceil(max(T), 64)
@@ -458,7 +541,7 @@ class ReadEngine:
             n_img = grids[r][1] * grids[r][2] // c.merge ** 2
             if len(m) != n_img:
                 raise ValueError(f"read {r}: {len(m)} image placeholders but the page yields {n_img} image tokens")
-            img_row[r, m] = first[r] + np.arange(n_img, dtype=np.int32)
+            img_row[r, m] = tok_rows[r]
             pos3[:, r, : T[r]], delta[r] = imageproc.mrope_positions(p, c.image_token_id, [grids[r]], c.merge)
         if int(pos3.max()) + max_new + 2 > self.max_pos:
             raise ValueError("rope table too short for this prompt")

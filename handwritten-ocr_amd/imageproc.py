@@ -64,6 +64,26 @@ def vision_positions(gh: int, gw: int, merge: int) -> tuple[np.ndarray, np.ndarr
     return blocks(hp), blocks(wp)
 
 
+def window_order(gh: int, gw: int, merge: int, window_size: int, patch: int) -> tuple[np.ndarray, np.ndarray]:
+    """Window partition of the Qwen2.5-VL tower for one gh x gw patch grid (HF vision_utils.py:130-188).
+
+    Returns (order, win_lens): `order[j]` = index (row-major over the merged gh/merge x gw/merge grid) of the merged
+    token at position j once tokens are regrouped window by window (windows row-major, tokens row-major inside a
+    window); `win_lens[w]` = PATCHES (merge^2 per merged token) in the w-th non-empty window.  The library pads the
+    grid by `side - n % side` on each axis — a whole empty window row/column when n is already a multiple — and drops
+    the empty windows again, so only non-empty ones are listed."""
+    side = window_size // merge // patch
+    lh, lw = gh // merge, gw // merge
+    idx = np.arange(lh * lw, dtype=np.int32).reshape(lh, lw)
+    order, lens = [], []
+    for wy in range(0, lh, side):
+        for wx in range(0, lw, side):
+            tile = idx[wy: wy + side, wx: wx + side].reshape(-1)
+            order.append(tile)
+            lens.append(tile.size * merge * merge)
+    return np.concatenate(order), np.asarray(lens, dtype=np.int32)
+
+
 def mrope_positions(ids: np.ndarray, image_token_id: int, grids: list[tuple[int, int, int]], merge: int):
     """3-axis decoder positions of one prompt + the offset generated tokens continue from.
     HF modeling_qwen2_vl.py:944-1058: text runs count up on all axes; an image run gets (t, h, w) grid coordinates

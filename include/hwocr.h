@@ -64,15 +64,24 @@ int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, void* O, co
                        long k_seg, long k_head, long k_row, long v_seg, long v_head, long v_row, long o_seg,
                        long o_row, float scale, int kv_tiled, hwocr_stream_t stream);
 
+/* Packed ragged segments, non-causal, one kv head per query head: segment s owns rows seg_off[s] .. +lens[s] of the
+ * shared [rows] axis (seg_off % 4 == 0).  The windowed layers of the Qwen2.5-VL vision tower
+ * (HF modeling_qwen2_5_vl.py:262-285 with cu_window_seqlens).  VT must be readable 64 keys past the last segment start. */
+int hwocr_attn_varlen(const void* Q, const void* K, const void* VT, void* O, const int* seg_off, const int* lens,
+                      int nseg, int heads, int head_dim, int max_len, long q_head, long q_row, long k_head,
+                      long k_row, long v_head, long v_row, long o_row, float scale, hwocr_stream_t stream);
+
 /* One query token per read against its KV cache (HF modeling_qwen2_vl.py:553-569 with q_len == 1). head_dim 128.
  * kv_tiled (here and in the cache writers below): the cache is in the fragment-tiled layout, strides k_row/v_row unused. */
 int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out, float* part_o,
                       float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head, long v_seq,
                       long v_head, long v_row, float scale, int kv_tiled, hwocr_stream_t stream);
 
-/* uint8 HWC resized pages -> bf16 patch rows (HF image_processing_pil_qwen2_vl.py:152-187, :226-229). */
+/* uint8 HWC resized pages -> bf16 patch rows (HF image_processing_pil_qwen2_vl.py:152-187, :226-229).
+ * row_src (optional, device int32 [gh*gw]): output row r of every image shows patch row_src[r] of the processor's
+ * merge-block-major order — the window permutation of the Qwen2.5-VL tower (HF modeling_qwen2_5_vl.py:441-444). */
 int hwocr_patchify(const void* img, const void* lut, void* out, int nimg, int H, int W, int patch, int merge,
-                   int tps, int kpad, int rows_per_img_ld, hwocr_stream_t stream);
+                   int tps, int kpad, int rows_per_img_ld, const int* row_src, hwocr_stream_t stream);
 
 int hwocr_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int D, int ldx, int ldo,
                     float eps, hwocr_stream_t stream);
@@ -107,12 +116,18 @@ int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_
 
 /* ---- model-level entry points (what run_ocr's model.generate expands to) ----------------------------------- */
 
+#define HWOCR_VIT_QWEN2 0   /* LayerNorm, fc1 -> QuickGELU -> fc2 (HF modeling_qwen2_vl.py:421-437) */
+#define HWOCR_VIT_QWEN2_5 1 /* RMSNorm, biased gate/up/down SiLU MLP, windowed attention (HF modeling_qwen2_5_vl.py:293-322) */
+
 typedef struct {
+  /* QWEN2_5: ln*_b unused; fc1_w/fc1_b = gate_proj/up_proj rows interleaved in 16-row tiles [2*mlp_dim][dim] (+ bias
+   * likewise), fc2 = down_proj [dim][mlp_dim]; mlp_dim is the intermediate size zero-padded to a multiple of 64 */
   const void *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  int windowed; /* QWEN2_5: attention inside windows (layer not in fullatt_block_indexes) */
 } hwocr_vit_block;
 
 typedef struct {
-  int depth, dim, heads, mlp_dim, patch, merge, tps, kpad, out_dim;
+  int depth, dim, heads, mlp_dim, patch, merge, tps, kpad, out_dim, kind;
   float eps;
   const void* patch_w;            /* [dim][kpad], zero beyond 3*tps*patch^2 */
   const hwocr_vit_block* blocks;  /* host array[depth] of device pointers */
@@ -121,14 +136,22 @@ typedef struct {
   const void* pixel_lut;            /* bf16 [3][256] */
 } hwocr_vit;
 
-typedef struct { /* all device buffers, rows = nimg * rows_per_img_ld */
+typedef struct { /* all device buffers, rows = nimg * rows_per_img_ld; vt holds 64 elements of slack past rows*dim */
   void *patches, *x, *xn, *qkv, *q, *k, *vt, *attn, *mlp, *merge_mid;
 } hwocr_vit_ws;
 
-/* images: uint8 [nimg][H][W][3] already resized to multiples of patch*merge; out: [rows/merge^2][out_dim] */
+typedef struct { /* device index tables of one batch of equally sized pages */
+  const int *pos_h, *pos_w; /* [rows] patch coordinates in buffer-row order */
+  const int *seg_lens;      /* [nimg] real patches per page */
+  const int *row_src;       /* [gh*gw] window permutation handed to hwocr_patchify, or NULL */
+  const int *win_off, *win_lens; /* [nwin] windows of the whole batch as row ranges (QWEN2_5), or NULL */
+  int nwin, max_win;
+} hwocr_vit_layout;
+
+/* images: uint8 [nimg][H][W][3] already resized to multiples of patch*merge; out: [rows/merge^2][out_dim], in buffer-row
+ * order (with row_src: window order — the caller's splice table undoes it, HF modeling_qwen2_5_vl.py:474-476) */
 int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, const void* images, int nimg, int H, int W,
-                      int rows_per_img_ld, const int* pos_h, const int* pos_w, const int* seg_lens, void* out,
-                      hwocr_stream_t stream);
+                      int rows_per_img_ld, const hwocr_vit_layout* layout, void* out, hwocr_stream_t stream);
 
 typedef struct {
   const void *in_norm_w, *qkv_w, *qkv_b, *o_w, *post_norm_w, *gate_up_w, *down_w;

@@ -1,12 +1,13 @@
 """ORACLE — test infrastructure, not product code.
 
 CPU restatement (plain torch ops, batch 1, no transformers import) of the arithmetic the reference's
-``run_ocr`` executes for the Qwen2-VL family: ``model.generate`` at ocr_agent/tools.py:764-765, i.e. the
+``run_ocr`` executes for the Qwen2-VL and Qwen2.5-VL (olmOCR-2, the reference's default OCR_MODEL, config.py:15)
+families: ``model.generate`` at ocr_agent/tools.py:764-765, i.e. the
 third-party library transformers (reference pins 5.1.0, poetry.lock:5252-5253; validated here against the
 installed 5.15.0).  The algorithm lives in that dependency, so every function cites the HF file:line it follows
 (HF = site-packages/transformers).
 
-Pinned by tests/golden/qwen2vl_tiny_*.safetensors: outputs of the real HF classes on seeded random-init models,
+Pinned by tests/golden/qwen2vl_tiny_*.safetensors and qwen25vl_tiny_*.safetensors: outputs of the real HF classes on seeded random-init models,
 written by tools/make_goldens.py in the build container (the reference repo itself holds no test or fixture for
 this path — SURVEY.md §4).
 
@@ -31,6 +32,11 @@ class RefConfig:
     patch_size: int = 14
     merge: int = 2
     tps: int = 2
+    # Qwen2.5-VL tower (HF models/qwen2_5_vl/configuration_qwen2_5_vl.py:36-66); family "qwen2_vl" ignores these
+    family: str = "qwen2_vl"
+    vit_inter: int = 0
+    window_size: int = 112
+    fullatt: tuple = (7, 15, 23, 31)
     # decoder (… :83-102)
     hidden: int = 1536
     layers: int = 28
@@ -96,6 +102,22 @@ def vision_position_ids(gh: int, gw: int, merge: int) -> torch.Tensor:
     return torch.stack([blockify(hp), blockify(wp)], dim=-1)
 
 
+def window_index(gh: int, gw: int, merge: int, window_size: int, patch: int):
+    """Window regrouping of one image's merged tokens.  HF vision_utils.py:130-188: the merged grid is padded with -100
+    to whole windows of side window_size // merge // patch (a full extra window when already a multiple), windows are
+    flattened row-major and the padding dropped.  Returns (window_index [lh*lw], patches per non-empty window)."""
+    side = window_size // merge // patch
+    lh, lw = gh // merge, gw // merge
+    idx = torch.arange(lh * lw).reshape(lh, lw)
+    ph, pw = side - lh % side, side - lw % side
+    padded = F.pad(idx, (0, pw, 0, ph), value=-100)
+    nh, nw = (lh + ph) // side, (lw + pw) // side
+    win = padded.reshape(nh, side, nw, side).permute(0, 2, 1, 3).reshape(nh * nw, side * side)
+    counts = (win != -100).sum(-1)
+    flat = win.reshape(-1)
+    return flat[flat != -100], (counts[counts > 0] * merge * merge).tolist()
+
+
 def rope_index(input_ids: torch.Tensor, image_token_id: int, grids: list[tuple[int, int, int]], merge: int):
     """3-axis M-RoPE position ids for one sequence.  HF modeling_qwen2_vl.py:944-1058 (get_rope_index) +
     :878-925 (get_vision_position_ids).  Returns (pos [3,T] int64, rope_delta int)."""
@@ -144,6 +166,8 @@ class Qwen2VLRef:
     def vision(self, pixel_values: torch.Tensor, grids: list[tuple[int, int, int]]) -> torch.Tensor:
         """HF modeling_qwen2_vl.py:700-729.  pixel_values fp32 [P, 1176] (all images concatenated)."""
         c = self.c
+        if c.family == "qwen2_5_vl":
+            return self.vision25(pixel_values, grids)
         P = pixel_values.shape[0]
         pre = "model.visual."
         # PatchEmbed: Conv3d with kernel == stride == whole patch, no bias == one matmul (:266-274)
@@ -189,6 +213,67 @@ class Qwen2VLRef:
         y = y.view(-1, c.embed_dim * c.merge * c.merge)
         y = F.gelu(F.linear(y, self.w(m + "mlp.0.weight"), self.w(m + "mlp.0.bias")))
         y = F.linear(y, self.w(m + "mlp.2.weight"), self.w(m + "mlp.2.bias"))
+        self.trace["merger"] = y
+        return y
+
+    def vision25(self, pixel_values: torch.Tensor, grids: list[tuple[int, int, int]]) -> torch.Tensor:
+        """Qwen2.5-VL tower, HF modeling_qwen2_5_vl.py:407-481: RMSNorm blocks, biased SiLU-gated MLP (:84-96), tokens
+        regrouped window by window (:441-450), attention inside windows except in `fullatt` layers (:452-465), merger
+        output put back in raster order (:474-476).  Single-frame images only (t == 1), as the reference feeds."""
+        c = self.c
+        P = pixel_values.shape[0]
+        pre = "model.visual."
+        mm = c.merge * c.merge
+        x = F.linear(pixel_values.to(self.dtype), self.w(pre + "patch_embed.proj.weight").reshape(c.embed_dim, -1))
+        self.trace["patch_embed"] = x
+        hd = c.vit_head_dim
+        inv = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float) / (hd // 2)))
+        pos = torch.cat([vision_position_ids(h, w, c.merge) for (_, h, w) in grids], dim=0)
+        rot = (pos.unsqueeze(-1) * inv).flatten(1)
+        order, win, seg = [], [0], [0]
+        base = 0
+        for (t, h, w) in grids:
+            assert t == 1
+            wi, lens = window_index(h, w, c.merge, c.window_size, c.patch_size)
+            order.append(wi + base)
+            for n in lens:
+                win.append(win[-1] + n)
+            base += h * w // mm
+            seg.append(seg[-1] + h * w)
+        order = torch.cat(order)
+        x = x.reshape(P // mm, mm, -1)[order].reshape(P, -1)
+        rot = rot.reshape(P // mm, mm, -1)[order].reshape(P, -1)
+        emb = torch.cat((rot, rot), dim=-1)
+        cos, sin = emb.cos().unsqueeze(-2), emb.sin().unsqueeze(-2)
+        for l in range(c.depth):
+            b = f"{pre}blocks.{l}."
+            y = rms_norm(x, self.w(b + "norm1.weight"), 1e-6)
+            qkv = F.linear(y, self.w(b + "attn.qkv.weight"), self.w(b + "attn.qkv.bias"))
+            q, k, v = qkv.reshape(P, 3, c.num_heads, hd).permute(1, 0, 2, 3).unbind(0)
+            qf, kf = q.float(), k.float()
+            q = (qf * cos + rotate_half(qf) * sin).to(self.dtype)
+            k = (kf * cos + rotate_half(kf) * sin).to(self.dtype)
+            cu = seg if l in c.fullatt else win
+            outs = []
+            for s in range(len(cu) - 1):
+                sl = slice(cu[s], cu[s + 1])
+                o = F.scaled_dot_product_attention(q[sl].transpose(0, 1).unsqueeze(0), k[sl].transpose(0, 1).unsqueeze(0),
+                                                   v[sl].transpose(0, 1).unsqueeze(0), scale=hd ** -0.5)
+                outs.append(o.squeeze(0).transpose(0, 1).reshape(cu[s + 1] - cu[s], c.embed_dim))
+            a = torch.cat(outs, dim=0)
+            x = x + F.linear(a, self.w(b + "attn.proj.weight"), self.w(b + "attn.proj.bias"))
+            y = rms_norm(x, self.w(b + "norm2.weight"), 1e-6)
+            g = F.silu(F.linear(y, self.w(b + "mlp.gate_proj.weight"), self.w(b + "mlp.gate_proj.bias")))
+            u = F.linear(y, self.w(b + "mlp.up_proj.weight"), self.w(b + "mlp.up_proj.bias"))
+            x = x + F.linear(g * u, self.w(b + "mlp.down_proj.weight"), self.w(b + "mlp.down_proj.bias"))
+            if l == 0:
+                self.trace["vit_block0"] = x
+        self.trace["vit_last"] = x
+        m = pre + "merger."
+        y = rms_norm(x, self.w(m + "ln_q.weight"), 1e-6).view(-1, c.embed_dim * mm)
+        y = F.gelu(F.linear(y, self.w(m + "mlp.0.weight"), self.w(m + "mlp.0.bias")))
+        y = F.linear(y, self.w(m + "mlp.2.weight"), self.w(m + "mlp.2.bias"))
+        y = y[torch.argsort(order)]
         self.trace["merger"] = y
         return y
 

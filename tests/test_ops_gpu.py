@@ -33,9 +33,11 @@ def _epilogue_ref(acc, bias, res, epi):
     raise AssertionError
 
 
-def _swiglu_ref(acc):
-    # weight rows interleaved [16 gate][16 up]
+def _swiglu_ref(acc, bias=None):
+    # weight (and bias) rows interleaved [16 gate][16 up]
     M, N = acc.shape
+    if bias is not None:
+        acc = acc + bias.float()
     a = acc.view(M, N // 32, 2, 16)
     g, u = rbf(a[:, :, 0, :]), rbf(a[:, :, 1, :])
     return (rbf(torch.nn.functional.silu(g)) * u).reshape(M, N // 2)
@@ -62,16 +64,25 @@ def test_gemm_wide(M, N, K, epi):
     assert_close_bf16(out, want, ulps=2.0, atol=2e-3, what=f"gemm_wide epi={epi}", mag=mag)
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (129, 17920 // 10, 1536), (1328, 1792, 1536), (2100, 608, 192)])
-def test_gemm_wide_swiglu(M, N, K):
+# with_bias: the Qwen2.5-VL vision MLP (gate_proj / up_proj carry a bias); (5184, 6912, 1280) is its page shape
+@pytest.mark.parametrize("with_bias", [False, True])
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (129, 17920 // 10, 1536), (1328, 1792, 1536), (2100, 608, 192),
+                                   (5184, 6912, 1280)])
+def test_gemm_wide_swiglu(M, N, K, with_bias):
     N = (N // 32) * 32
     x = randbf(M, K, seed=5)
     w = randbf(N, K, scale=K ** -0.5, seed=6)
+    bias = randbf(N, scale=0.5, seed=7) if with_bias else None
     out = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
-    rc = lib().hwocr_gemm_wide(p(x), p(w), None, None, p(out), M, N, K, K, K, N // 2, 0, 4, st())
+    rc = lib().hwocr_gemm_wide(p(x), p(w), p(bias) if with_bias else None, None, p(out), M, N, K, K, K, N // 2, 0, 4, st())
     assert rc == 0
     sync()
-    assert_close_bf16(out, _swiglu_ref(x.float() @ w.float().t()), ulps=3.0, atol=2e-3, what="gemm_wide swiglu")
+    acc = x.float() @ w.float().t()
+    want = _swiglu_ref(acc, bias)
+    # a 1-ulp flip of the rounded gate g moves silu(g) by up to (1 + |g|) ulps (silu'(g)/silu(g) ~ 1 + 1/g for g << 0):
+    # the ulp budget is taken at |out| * (1 + |g|)
+    gate = rbf((acc + (bias.float() if with_bias else 0.0)).view(M, N // 32, 2, 16)[:, :, 0, :]).reshape(M, N // 2)
+    assert_close_bf16(out, want, ulps=3.0, atol=2e-3, what="gemm_wide swiglu", mag=want.abs() * (1.0 + gate.abs()))
 
 
 def test_gemm_wide_rejects_bad_shapes():
@@ -176,6 +187,35 @@ def test_attn_prefill(hd, Hq, Hkv, causal, tiled):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize("hd,heads", [(80, 4), (32, 2)])
+def test_attn_varlen_windows(hd, heads):
+    """Ragged windows packed on one row axis (Qwen2.5-VL windowed layers): starts are multiples of 4 rows only."""
+    lens = [64, 16, 32, 4, 64, 36, 8, 48, 12, 64]
+    offs = [0]
+    for n in lens[:-1]:
+        offs.append(offs[-1] + n)
+    rows = 384  # buffer rows (multiple of 64) >= sum(lens) = 348; rows past the last window are padding
+    assert offs[-1] + lens[-1] <= rows
+    q = randbf(heads, rows, hd, seed=31)
+    k = randbf(heads, rows, hd, seed=32)
+    v = randbf(heads, rows, hd, seed=33)
+    vt = torch.zeros(heads * hd * rows + 64, dtype=torch.bfloat16, device=DEV)  # 64 elements of slack, as the ABI asks
+    vt[: heads * hd * rows] = v.transpose(1, 2).reshape(-1)
+    out = torch.zeros(rows, heads * hd, dtype=torch.bfloat16, device=DEV)
+    off_d = torch.tensor(offs, dtype=torch.int32, device=DEV)
+    len_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    scale = hd ** -0.5
+    rc = lib().hwocr_attn_varlen(p(q), p(k), p(vt), p(out), p(off_d), p(len_d), len(lens), heads, hd, max(lens),
+                                 rows * hd, hd, rows * hd, hd, hd * rows, rows, heads * hd, scale, st())
+    assert rc == 0
+    sync()
+    for o, n in zip(offs, lens):
+        want = _sdpa_ref(q[:, o: o + n].float(), k[:, o: o + n].float(), v[:, o: o + n].float(), False, scale)
+        got = out[o: o + n].view(n, heads, hd)
+        assert_close_bf16(got, want, ulps=4.0, atol=4e-3, what=f"attn_varlen window at {o}")
+    assert (out[offs[-1] + lens[-1]:] == 0).all(), "rows outside every window must stay untouched"
+
+
 @pytest.mark.parametrize("tiled", [0, 1])
 @pytest.mark.parametrize("nsplit", [1, 4])
 def test_attn_decode(nsplit, tiled):
@@ -218,7 +258,9 @@ def test_layernorm(rows, D):
     assert_close_bf16(out, want, ulps=1.0, atol=1e-3, what="layernorm")
 
 
-@pytest.mark.parametrize("rows,D,nslab", [(7, 1536, 0), (96, 1536, 6), (3, 256, 2)])
+# D = 3584: Qwen2.5-VL-7B hidden size (512-thread row kernel / 7 chunks per lane); 1280 x 600 rows: its vision tower
+@pytest.mark.parametrize("rows,D,nslab", [(7, 1536, 0), (96, 1536, 6), (3, 256, 2), (126, 3584, 4), (600, 3584, 0),
+                                          (600, 1280, 0), (5, 4096, 3)])
 def test_add_rmsnorm(rows, D, nslab):
     h = randbf(rows, D, scale=2.0, seed=21)
     w = randbf(D, seed=22)
@@ -255,7 +297,8 @@ def test_add_rmsnorm_gather():
     assert_close_bf16(out, want, ulps=1.5, atol=1e-3, what="rmsnorm gather")
 
 
-def test_patchify_exact():
+@pytest.mark.parametrize("permuted", [False, True])
+def test_patchify_exact(permuted):
     nimg, H, W, patch, merge, tps = 2, 56, 84, 14, 2, 2
     kreal, kpad = 3 * tps * patch * patch, 1216
     g = torch.Generator().manual_seed(26)
@@ -266,14 +309,18 @@ def test_patchify_exact():
     ld = 64
     out = torch.full((nimg * ld, kpad), 7.0, dtype=torch.bfloat16, device=DEV)
     img_d, lut_d = img.to(DEV), lut.to(DEV)  # keep alive: the launch only sees raw pointers
-    rc = lib().hwocr_patchify(p(img_d), p(lut_d), p(out), nimg, H, W, patch, merge, tps, kpad, ld, st())
+    # permuted: output row r shows source patch row_src[r] (the window order of the Qwen2.5-VL tower)
+    src = torch.randperm(P, generator=g).to(torch.int32) if permuted else torch.arange(P, dtype=torch.int32)
+    src_d = src.to(DEV)
+    rc = lib().hwocr_patchify(p(img_d), p(lut_d), p(out), nimg, H, W, patch, merge, tps, kpad, ld,
+                              p(src_d) if permuted else None, st())
     assert rc == 0
     sync()
     # restatement of HF patchify on the LUT-mapped image (C,H,W)
     for im in range(nimg):
         chw = torch.stack([lut[c][img[im, :, :, c].long()] for c in range(3)])  # [3,H,W] bf16
         x = chw.reshape(3, gh // merge, merge, patch, gw // merge, merge, patch).permute(1, 4, 2, 5, 0, 3, 6)
-        x = x.unsqueeze(5).expand(*x.shape[:5], tps, patch, patch).reshape(P, kreal)
+        x = x.unsqueeze(5).expand(*x.shape[:5], tps, patch, patch).reshape(P, kreal)[src.long()]
         got = out[im * ld: im * ld + P].cpu()
         assert torch.equal(got[:, :kreal], x), "patchify must be an exact gather"
         assert (got[:, kreal:] == 0).all()

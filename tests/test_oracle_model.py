@@ -4,23 +4,26 @@ import pytest
 import torch
 
 from oracle.qwen2vl_ref import Qwen2VLRef, rope_index
-from tests._golden import tiny_case, tiny_meta, tiny_ref_config, tiny_weights
+from tests._golden import FAMILIES, tiny_case, tiny_meta, tiny_ref_config, tiny_weights
 
 
+@pytest.mark.parametrize("family", FAMILIES)
 @pytest.mark.parametrize("tag,dtype", [("fp32", torch.float32), ("bf16", torch.bfloat16)])
 @pytest.mark.parametrize("case", ["a", "b"])
-def test_oracle_matches_hf(tag, dtype, case):
-    meta = tiny_meta()["cases"][case]
-    g = tiny_case(tag)
-    ref = Qwen2VLRef(tiny_ref_config(), tiny_weights(dtype))
+def test_oracle_matches_hf(tag, dtype, case, family):
+    meta = tiny_meta(family)["cases"][case]
+    g = tiny_case(tag, family)
+    ref = Qwen2VLRef(tiny_ref_config(family), tiny_weights(dtype, family))
     ids = g[f"{case}.input_ids"].long()
     grids = [tuple(meta["grid_thw"])]
     logits, cache, delta = ref.prefill(ids, g[f"{case}.pixel_values"], grids)
     assert delta == meta["rope_delta"]
     assert torch.equal(ref.trace["position_ids"].int(), g[f"{case}.position_ids"])
-    # fp32: same ops in the same order -> tight; bf16: identical module-level rounding points, so near bit-exact, but
-    # SDPA / matmul blocking may differ between call shapes -> 2 bf16 ulps of the tensor's scale
-    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    # fp32: same ops in the same order -> tight.  bf16: identical module-level rounding points; in the container that
+    # wrote the goldens every tensor below is bit-identical to HF's (the bf16 model is loaded with from_pretrained, so
+    # its rotary inv_freq buffers stay fp32 as in any real run).  The bound leaves room for another CPU's matmul
+    # blocking only: ~2 bf16 ulps of the tensor's scale.
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
     for name in ("patch_embed", "vit_block0", "vit_last", "merger", "dec_layer0"):
         want = g[f"{case}.{name}"].float()
         got = ref.trace[name].float()
@@ -32,12 +35,13 @@ def test_oracle_matches_hf(tag, dtype, case):
     assert torch.allclose(logits.float(), want, rtol=tol["rtol"], atol=tol["atol"] * max(1.0, float(want.abs().max())))
 
 
+@pytest.mark.parametrize("family", FAMILIES)
 @pytest.mark.parametrize("tag,dtype", [("fp32", torch.float32), ("bf16", torch.bfloat16)])
-def test_oracle_greedy_and_teacher_forced(tag, dtype):
+def test_oracle_greedy_and_teacher_forced(tag, dtype, family):
     case = "a"
-    meta = tiny_meta()["cases"][case]
-    g = tiny_case(tag)
-    ref = Qwen2VLRef(tiny_ref_config(), tiny_weights(dtype))
+    meta = tiny_meta(family)["cases"][case]
+    g = tiny_case(tag, family)
+    ref = Qwen2VLRef(tiny_ref_config(family), tiny_weights(dtype, family))
     ids = g[f"{case}.input_ids"].long()
     hf_tokens = g[f"{case}.greedy_tokens"].tolist()
     n = meta["n_new"]
@@ -66,3 +70,15 @@ def test_rope_index_text_only_and_two_images():
     assert pos[:, 9:11].tolist() == [[7, 7], [7, 7], [7, 8]]
     assert pos[:, 11].tolist() == [9, 9, 9]
     assert delta == 10 - 12
+
+
+@pytest.mark.parametrize("gh,gw", [(72, 72), (4, 6), (10, 14), (36, 20), (2, 2)])
+def test_window_index_partition(gh, gw):
+    """Every merged token appears once; windows are contiguous runs; 1008x1008 pages give 81 full 64-patch windows."""
+    from oracle.qwen2vl_ref import window_index
+
+    order, lens = window_index(gh, gw, 2, 112, 14)
+    n = (gh // 2) * (gw // 2)
+    assert sorted(order.tolist()) == list(range(n)) and sum(lens) == gh * gw
+    if (gh, gw) == (72, 72):
+        assert lens == [64] * 81

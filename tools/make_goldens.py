@@ -309,15 +309,30 @@ TINY = dict(
     image_token_id=500, video_token_id=501, vision_start_token_id=502, vision_end_token_id=503, eos=510, pad=511)
 
 
-def build_tiny_hf(dtype: torch.dtype):
-    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+# Qwen2.5-VL (the olmOCR-2 family, the reference's default OCR_MODEL): windows of 2x2 merged tokens, so the test pages
+# have ragged windows on both axes; layer 1 of 3 attends over the whole page.  intermediate_size 88 is NOT a multiple
+# of 64, like the real tower's 3420 (the engine zero-pads it).
+TINY25 = dict(
+    vision=dict(depth=3, hidden_size=64, out_hidden_size=256, hidden_act="silu", intermediate_size=88, num_heads=2,
+                in_channels=3, patch_size=14, spatial_merge_size=2, temporal_patch_size=2, window_size=56,
+                fullatt_block_indexes=[1]),
+    text=dict(TINY["text"]),
+    image_token_id=500, video_token_id=501, vision_start_token_id=502, vision_end_token_id=503, eos=510, pad=511)
 
-    cfg = Qwen2VLConfig(vision_config=dict(TINY["vision"]), text_config=dict(TINY["text"]),
-                        image_token_id=TINY["image_token_id"], video_token_id=TINY["video_token_id"],
-                        vision_start_token_id=TINY["vision_start_token_id"], vision_end_token_id=TINY["vision_end_token_id"],
-                        tie_word_embeddings=True)
+
+def build_tiny_hf(dtype: torch.dtype, family: str = "qwen2_vl"):
+    if family == "qwen2_vl":
+        from transformers import Qwen2VLConfig as Cfg, Qwen2VLForConditionalGeneration as Model
+        spec = TINY
+    else:
+        from transformers import Qwen2_5_VLConfig as Cfg, Qwen2_5_VLForConditionalGeneration as Model
+        spec = TINY25
+    cfg = Cfg(vision_config=dict(spec["vision"]), text_config=dict(spec["text"]),
+              image_token_id=spec["image_token_id"], video_token_id=spec["video_token_id"],
+              vision_start_token_id=spec["vision_start_token_id"], vision_end_token_id=spec["vision_end_token_id"],
+              tie_word_embeddings=True)
     torch.manual_seed(0)
-    model = Qwen2VLForConditionalGeneration(cfg).eval()
+    model = Model(cfg).eval()
     g = torch.Generator().manual_seed(20260504)
     with torch.no_grad():
         for name, prm in sorted(model.named_parameters()):
@@ -332,10 +347,22 @@ def build_tiny_hf(dtype: torch.dtype):
                 v = torch.randn(prm.shape, generator=g) * (1.5 / (prm.shape[-1] if prm.dim() < 3 else prm[0].numel()) ** 0.5)
             prm.copy_(v.to(torch.bfloat16).to(prm.dtype))  # bf16-representable, so one weight file serves both dtypes
     model.tie_weights()
-    return model.to(dtype), cfg
+    if dtype == torch.float32:
+        return model, cfg
+    # Load the way the reference does (from_pretrained(..., dtype=bf16), ocr_agent/tools.py:700-716): parameters become
+    # bf16 but the rotary inv_freq buffers stay fp32.  `model.to(bf16)` would round those buffers too — an artefact no
+    # real run has.
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        model.save_pretrained(tmp)
+        model = Model.from_pretrained(tmp, dtype=dtype).eval()
+    assert model.model.visual.rotary_pos_emb.inv_freq.dtype == torch.float32
+    assert model.model.language_model.rotary_emb.inv_freq.dtype == torch.float32
+    return model, cfg
 
 
-def make_model() -> None:
+def make_model(family: str = "qwen2_vl") -> None:
     from safetensors.torch import save_file
     from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
     from PIL import Image
@@ -344,16 +371,18 @@ def make_model() -> None:
     cases = [("a", 11, (60, 90)), ("b", 12, (150, 200))]
     rng = np.random.default_rng(77)
     weights_saved = False
-    meta = {"config": {k: v for k, v in TINY.items()}, "cases": {}, "source": "transformers Qwen2VLForConditionalGeneration, "
-            "random init (seeded), greedy, min_new_tokens == max_new_tokens"}
+    spec, stem = (TINY, "qwen2vl_tiny") if family == "qwen2_vl" else (TINY25, "qwen25vl_tiny")
+    meta = {"config": {k: v for k, v in spec.items()}, "cases": {}, "family": family,
+            "source": "transformers %s, random init (seeded), greedy, min_new_tokens == max_new_tokens"
+                      % ("Qwen2VLForConditionalGeneration" if family == "qwen2_vl" else "Qwen2_5_VLForConditionalGeneration")}
     N_NEW = 24
     for dtype, tag in [(torch.float32, "fp32"), (torch.bfloat16, "bf16")]:
-        model, cfg = build_tiny_hf(dtype)
+        model, cfg = build_tiny_hf(dtype, family)
         model.generation_config.eos_token_id = TINY["eos"]
         model.generation_config.pad_token_id = TINY["pad"]
         if not weights_saved:
             sd = {k: v.to(torch.bfloat16).contiguous() for k, v in model.state_dict().items() if k != "lm_head.weight"}
-            save_file(sd, os.path.join(GOLD, "qwen2vl_tiny_weights.safetensors"))
+            save_file(sd, os.path.join(GOLD, f"{stem}_weights.safetensors"))
             weights_saved = True
         tensors = {}
         for cname, seed, (h, w) in cases:
@@ -376,7 +405,9 @@ def make_model() -> None:
 
             vis = model.model.visual
             hs = [vis.patch_embed.register_forward_hook(hook("patch_embed")), vis.blocks[0].register_forward_hook(hook("vit_block0")),
-                  vis.blocks[-1].register_forward_hook(hook("vit_last")), vis.merger.register_forward_hook(hook("merger")),
+                  vis.blocks[-1].register_forward_hook(hook("vit_last")),
+                  # the tower's pooled output: for Qwen2.5-VL the merger rows put back in raster order
+                  vis.register_forward_hook(lambda m_, i_, o_: acts.__setitem__("merger", o_.pooler_output.detach().clone())),
                   model.model.language_model.layers[0].register_forward_hook(hook("dec_layer0"))]
             with torch.no_grad():
                 fw = model(input_ids=input_ids, pixel_values=pv, image_grid_thw=grid, mm_token_type_ids=mm,
@@ -400,15 +431,17 @@ def make_model() -> None:
                 tensors[f"{cname}.{k}"] = (v[0] if v.dim() == 3 else v).contiguous()
             meta["cases"][cname] = {"page_seed": seed, "page_hw": [h, w], "grid_thw": grid[0].tolist(), "n_new": N_NEW,
                                     "rope_delta": int(delta[0]), "T": len(ids)}
-        save_file(tensors, os.path.join(GOLD, f"qwen2vl_tiny_{tag}.safetensors"))
-        print(f"qwen2vl_tiny_{tag}.safetensors:", {k: tuple(v.shape) for k, v in tensors.items() if k.startswith("a.")})
-    with open(os.path.join(GOLD, "qwen2vl_tiny.json"), "w") as f:
+        save_file(tensors, os.path.join(GOLD, f"{stem}_{tag}.safetensors"))
+        print(f"{stem}_{tag}.safetensors:", {k: tuple(v.shape) for k, v in tensors.items() if k.startswith("a.")})
+    with open(os.path.join(GOLD, f"{stem}.json"), "w") as f:
         json.dump(meta, f, indent=0)
+    for fn in os.listdir(GOLD):  # safetensors writes 0600; the GPU box reads the snapshot as another user
+        os.chmod(os.path.join(GOLD, fn), 0o644)
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="text,preprocess,nodes,image,model")
+    ap.add_argument("--only", default="text,preprocess,nodes,image,model,model25")
     only = set(ap.parse_args().only.split(","))
     os.makedirs(GOLD, exist_ok=True)
     if only & {"text", "preprocess"}:
@@ -422,7 +455,9 @@ def main() -> None:
     if "image" in only:
         make_image()
     if "model" in only:
-        make_model()
+        make_model("qwen2_vl")
+    if "model25" in only:
+        make_model("qwen2_5_vl")
 
 
 if __name__ == "__main__":
