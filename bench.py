@@ -34,6 +34,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+WORKLOAD_NAMES = {"qwen2-vl-2b": "Qwen2-VL-2B", "qwen2.5-vl-7b": "Qwen2.5-VL-7B / olmOCR-2-7B", "qwen2.5-vl-3b": "Qwen2.5-VL-3B"}
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0
 
@@ -87,37 +88,19 @@ def cpu_baseline(cfg, side: int, n_out: int, reads_per_page: int) -> dict:
         avail = os.cpu_count() or 1
     threads = max(1, min(torch.get_num_threads(), avail, 16))
     torch.set_num_threads(threads)
-    g = torch.Generator().manual_seed(0)
+    import dataclasses
 
-    def rn(*shape):
-        return (torch.randn(*shape, generator=g) * 0.02).to(torch.bfloat16)
+    from handwritten_ocr_amd import engine
 
-    D, H, MD = cfg.embed_dim, cfg.hidden, cfg.embed_dim * 4
-    sd = {"model.visual.patch_embed.proj.weight": rn(D, 3, 2, 14, 14), "model.language_model.embed_tokens.weight": rn(cfg.vocab, H),
-          "model.language_model.norm.weight": torch.ones(H, dtype=torch.bfloat16),
-          "model.visual.merger.ln_q.weight": torch.ones(D, dtype=torch.bfloat16), "model.visual.merger.ln_q.bias": rn(D),
-          "model.visual.merger.mlp.0.weight": rn(MD, MD), "model.visual.merger.mlp.0.bias": rn(MD),
-          "model.visual.merger.mlp.2.weight": rn(H, MD), "model.visual.merger.mlp.2.bias": rn(H)}
-    for l in range(2):
-        b = f"model.visual.blocks.{l}."
-        sd.update({b + "norm1.weight": torch.ones(D, dtype=torch.bfloat16), b + "norm1.bias": rn(D),
-                   b + "norm2.weight": torch.ones(D, dtype=torch.bfloat16), b + "norm2.bias": rn(D),
-                   b + "attn.qkv.weight": rn(3 * D, D), b + "attn.qkv.bias": rn(3 * D), b + "attn.proj.weight": rn(D, D),
-                   b + "attn.proj.bias": rn(D), b + "mlp.fc1.weight": rn(cfg.mlp_dim, D), b + "mlp.fc1.bias": rn(cfg.mlp_dim),
-                   b + "mlp.fc2.weight": rn(D, cfg.mlp_dim), b + "mlp.fc2.bias": rn(D)})
-        p = f"model.language_model.layers.{l}."
-        sd.update({p + "input_layernorm.weight": torch.ones(H, dtype=torch.bfloat16),
-                   p + "post_attention_layernorm.weight": torch.ones(H, dtype=torch.bfloat16),
-                   p + "self_attn.q_proj.weight": rn(cfg.q_heads * 128, H), p + "self_attn.q_proj.bias": rn(cfg.q_heads * 128),
-                   p + "self_attn.k_proj.weight": rn(cfg.kv_heads * 128, H), p + "self_attn.k_proj.bias": rn(cfg.kv_heads * 128),
-                   p + "self_attn.v_proj.weight": rn(cfg.kv_heads * 128, H), p + "self_attn.v_proj.bias": rn(cfg.kv_heads * 128),
-                   p + "self_attn.o_proj.weight": rn(H, cfg.q_heads * 128), p + "mlp.gate_proj.weight": rn(cfg.inter, H),
-                   p + "mlp.up_proj.weight": rn(cfg.inter, H), p + "mlp.down_proj.weight": rn(H, cfg.inter)})
+    # two layers of each stack at full widths, HF parameter names (family-specific tower included)
+    sd = engine.random_state_dict(dataclasses.replace(cfg, depth=2, layers=2), seed=0, device="cpu")
 
-    def ref(depth, layers):
-        rc = RefConfig(depth=depth, embed_dim=D, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, hidden=H, layers=layers,
-                       q_heads=cfg.q_heads, kv_heads=cfg.kv_heads, inter=cfg.inter, vocab=cfg.vocab,
-                       image_token_id=cfg.image_token_id, vision_start_id=cfg.vision_start_id,
+    def ref(depth, layers, fullatt=()):
+        rc = RefConfig(depth=depth, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                       family=cfg.family, vit_inter=cfg.vit_inter, window_size=cfg.window_size,
+                       fullatt=tuple(fullatt),
+                       hidden=cfg.hidden, layers=layers, q_heads=cfg.q_heads, kv_heads=cfg.kv_heads, inter=cfg.inter,
+                       vocab=cfg.vocab, tie=cfg.tie, image_token_id=cfg.image_token_id, vision_start_id=cfg.vision_start_id,
                        vision_end_id=cfg.vision_end_id, eos_ids=tuple(cfg.eos_ids), pad_id=cfg.pad_id)
         return Qwen2VLRef(rc, sd)
 
@@ -135,6 +118,9 @@ def cpu_baseline(cfg, side: int, n_out: int, reads_per_page: int) -> dict:
     with torch.no_grad():
         t_v1, emb = timed(lambda: ref(1, 1).vision(pvt, [grid]))
         t_v2, _ = timed(lambda: ref(2, 1).vision(pvt, [grid]))
+        # Qwen2.5-VL: the two timings above are windowed layers; layers in fullatt attend over the whole page
+        n_full = sum(1 for i in cfg.fullatt if i < cfg.depth) if cfg.family == "qwen2_5_vl" else 0
+        t_vf = timed(lambda: ref(2, 1, fullatt=(0,)).vision(pvt, [grid]))[0] if n_full else t_v2
         n_img = emb.shape[0]
         ids = torch.from_numpy(synthetic_prompt(cfg, n_img)).long()
         T = len(ids)
@@ -156,14 +142,15 @@ def cpu_baseline(cfg, side: int, n_out: int, reads_per_page: int) -> dict:
         t_d2, _ = timed(lambda: [r2.step(5, c2, delta) for _ in range(n_dec)])
     t_d1, t_d2 = t_d1 / n_dec, t_d2 / n_dec
     dv, dp, dd = max(t_v2 - t_v1, 0.0), max(t_p2 - t_p1, 0.0), max(t_d2 - t_d1, 0.0)
-    t_read = t_img + (t_v1 + (cfg.depth - 1) * dv) + (t_p1 + (cfg.layers - 1) * dp) + (n_out - 1) * (t_d1 + (cfg.layers - 1) * dd)
+    t_vision = t_v1 + (cfg.depth - 1 - n_full) * dv + n_full * max(t_vf - t_v1, 0.0)
+    t_read = t_img + t_vision + (t_p1 + (cfg.layers - 1) * dp) + (n_out - 1) * (t_d1 + (cfg.layers - 1) * dd)
     rng = np.random.default_rng(1)
     words = ["".join(chr(97 + int(c)) for c in rng.integers(0, 26, size=int(rng.integers(2, 9)))) for _ in range(260)]
     texts = [" ".join(words)] + [" ".join(w if rng.random() > 0.1 else w[::-1] for w in words) for _ in range(2)]
     t_str, _ = timed(lambda: (text_ref.compare_versions(texts[0], texts[1]), text_ref.merge_versions(texts)))
     t_page = reads_per_page * t_read + t_str
     return {"value": 1.0 / t_page, "unit": "pages/s", "cores": threads, "kind": "port",
-            "sample": (f"oracle/ (torch CPU bf16 restatement of the HF Qwen2-VL path) at full Qwen2-VL-2B widths on one "
+            "sample": (f"oracle/ (torch CPU bf16 restatement of the HF {cfg.family} path) at full {cfg.name} widths on one "
                        f"{side}x{side} page: image processor + vision tower / decoder prefill (T={T}) / decode step timed with "
                        f"1 and 2 layers and extrapolated linearly to {cfg.depth}/{cfg.layers} layers; {n_dec} decode steps "
                        f"scaled to {n_out - 1}; compare+merge of three {len(texts[0])}-char reads in pure Python; "
@@ -271,7 +258,7 @@ def main() -> None:
         "metric": "handwritten pages/sec (1024x1024, 3-strategy reads)", "value": value, "unit": "pages/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"Qwen2-VL-2B shape (random init) x {args.side}x{args.side} synthetic handwritten pages, "
+        "config": {"workload": f"{WORKLOAD_NAMES.get(cfg.name, cfg.name)} shape (random init) x {args.side}x{args.side} synthetic handwritten pages, "
                                f"{args.reads} preprocessing-strategy reads per page, {args.new_tokens} greedy tokens per read",
                    "pages_per_step_per_gpu": args.pages, "reads_in_flight": n_reads, "prompt_tokens": T,
                    "image_tokens": int((prompts[0] == cfg.image_token_id).sum()), "new_tokens": args.new_tokens,

@@ -435,6 +435,17 @@ extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias,
     return HWOCR_EINVAL;
   if (epi != EPI_PARTIAL && splitk != 1) return HWOCR_EINVAL;
   if (epi == EPI_SWIGLU && bias) return HWOCR_EINVAL;
+  // up to 128 rows over fragment-tiled weights: the LDS-DMA streaming kernel (gemm_stream.hip)
+  static const bool use_stream = [] { const char* e = getenv("HWOCR_GEMM_STREAM"); return !e || atoi(e) != 0; }();
+  if (use_stream && w_tiled && Bsz <= 128 && (K % 64) == 0) {
+    const int ktiles = K / 64, per = (ktiles + splitk - 1) / splitk;
+    // a plain linear over more than one round of 16-tile groups (the LM head) re-stages x once per group: the older
+    // kernel's 128-row groups do that cheaper (LM head 2B: 90 us against 104)
+    const bool many_rounds = epi == EPI_LINEAR && N / 16 > 16 * 256;
+    if ((splitk - 1) * per < ktiles && !many_rounds)
+      return hwocr_gemm_stream(StreamArgs{(const bf16*)X, (const bf16*)W, (const bf16*)bias, out, Bsz, N, K, ldx, ldo, 0},
+                               epi, splitk, stream);
+  }
   // K slice per split: whole 256-element chunks
   int chunks = (K + 255) / 256;
   int per = (chunks + splitk - 1) / splitk;

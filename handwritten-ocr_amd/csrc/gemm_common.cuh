@@ -89,5 +89,13 @@ __device__ __forceinline__ void tile_of_block(int tilesM, int tilesN, int group,
 
 }  // namespace gemm
 
+// decode-step GEMM over fragment-tiled weights (gemm_stream.hip); out is bf16 [Bsz][ldo] or, for EPI_PARTIAL, fp32
+// slabs [splitk][Bsz][ldo]
+struct StreamArgs {
+  const bf16* X; const bf16* W; const bf16* bias; void* out;
+  int Bsz, N, K, ldx, ldo, ktiles_per_slice;
+};
+int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream);
+
 // launcher of the 256x256 kernel (gemm256.hip); returns HWOCR_EINVAL when the shape does not qualify
 int hwocr_gemm_wide256(const gemm::WideArgs& a, int epi, hipStream_t stream);

@@ -1,0 +1,252 @@
+// Decode-step GEMM: out[Bsz <= 128][N] = x[Bsz][K] . W[N][K]^T with W streamed from HBM exactly once.
+//
+// A decode step multiplies the same 1..128 activation rows (one per read in flight) by every decoder weight.  The
+// first decode kernel (gemm_skinny_kernel: weights HBM -> VGPR in two register stages, x chunks by LDS-DMA, 2-4 waves)
+// kept 4-8 KB in flight per wave and measured 1.7-3.1 TB/s of weights at 126 rows.  This kernel:
+//   * W is the fragment-tiled copy ([N/16][K/32][lane][8], hwocr_tile_weights): the K axis of a 16-row tile is ONE
+//     contiguous stream and a 1 KiB LDS-DMA instruction delivers one MFMA A fragment in lane order — the LDS image
+//     needs no swizzle, fragment reads are lane-linear ds_read_b128.
+//   * x K-tiles ride the same ring (LDS-DMA from L2): rows of 128 B, one instruction = 8 whole rows (whole cache
+//     lines), 16-byte chunks XOR-swizzled on the SOURCE address so that the B fragment reads are conflict-free.
+//   * ring of 3 stages of one 64-wide K tile: while tile t is multiplied, t+1 and t+2 are in flight; one raw s_barrier
+//     per K tile; each wave waits with a COUNTED vmcnt for its own DMAs only.
+//   * one workgroup of 16 waves per CU, wave w = weight tile w of the group x all MT row tiles.  Weight tiles are dealt
+//     to workgroups as balanced contiguous ranges of at most 16 tiles, so grid.x * splitk can be made ~256 (one round)
+//     whatever N is: 37888 rows (Qwen2.5-VL-7B gate/up) = 1184 tile pairs = 4.6 pairs per CU, 92 % balance.
+//     SwiGLU: the gate tile sits in the even wave and the up tile in the odd one; the up accumulators cross through the
+//     idle ring once at the end.
+// What bounds it (7B gate/up, 271 MB of weights, 126 rows): every workgroup must also pull the whole activation tile
+// (126 x K x 2 B) through L2 -> LDS, and the bytes entering the CUs top out near 8 TB/s chip-wide = 31-33 GB/s per CU —
+// the same per-CU rate the 256x256 prefill GEMM runs at, and the same whether the bytes come by LDS-DMA or by
+// global_load + ds_write.  Measured on the way: 4 waves 2.9 TB/s of weights, 8 waves 4.0, 16 waves 4.4-4.5 (16 rows
+// instead of 126, i.e. an 8x smaller x tile: 5.6 TB/s); time = (W + 256 x-tiles) / 8 TB/s within 5 % on every shape.
+// A variant with the weights HBM -> VGPR in a 4-deep hand-unrolled register ring (exact compiler vmcnt waits once the
+// loop has no separate prologue and no load under a t-dependent branch) and x by plain loads + ds_write ran at the same
+// bytes-into-CU ceiling but re-read weight tiles for idle waves: 3.3 TB/s; dropped.
+// Epilogues as gemm_skinny: PARTIAL fp32 split-K slabs, LINEAR (+bias), SWIGLU on interleaved gate/up tile pairs.
+#include "gemm_common.cuh"
+
+using namespace gemm;
+
+namespace {
+
+constexpr int WG_TILES = 16;               // weight tiles per workgroup
+constexpr int NSTAGE = 3;
+constexpr int WBYTES = WG_TILES * 2048;    // one K tile (64) of 16 weight tiles' fragments
+
+__device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of this wave's DMA instructions in flight
+  switch (pending) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+  }
+}
+
+// MT: 16-row activation tiles (Bsz <= 16 MT).  WAVES x NTW = 16 weight tiles.  grid = (tile groups, K slices).
+template <int MT, int EPI, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
+  constexpr int NTW = WG_TILES / WAVES;             // weight tiles per wave
+  constexpr int XFR = 2 * MT;                       // x DMA instructions (8 rows x 128 B = 1 KiB each) per K tile
+  constexpr int XPW = (XFR + WAVES - 1) / WAVES;    // staged per wave
+  constexpr int XBYTES = XFR * 1024;
+  constexpr int STAGE = XBYTES + WBYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+
+  // ---- this workgroup's weight tiles [t0, t1) (SwiGLU: whole gate/up pairs) and K tiles [kt0, kt0 + nk)
+  constexpr int UNIT = EPI == EPI_SWIGLU ? 2 : 1;
+  const int units = (a.N >> 4) / UNIT;
+  const int t0 = (int)((long)blockIdx.x * units / gridDim.x) * UNIT;
+  const int t1 = (int)((long)(blockIdx.x + 1) * units / gridDim.x) * UNIT;
+  const int my0 = t0 + w * NTW;
+  const int mine = max(0, min(NTW, t1 - my0));     // wave-uniform
+  const int kt0 = blockIdx.y * a.ktiles_per_slice;
+  const int nk = min(a.ktiles_per_slice, (a.K >> 6) - kt0);
+
+  // ---- DMA sources.  x instruction f stages rows 8f .. 8f+7: lane l <- 16-byte chunk (l&7) ^ (l>>3) of row 8f + (l>>3),
+  // so chunk ch of row r sits at LDS position ch ^ (r & 7) of its 128-byte row
+  const bf16* xsrc[XPW];
+#pragma unroll
+  for (int e = 0; e < XPW; ++e) {
+    const int f = w + WAVES * e;
+    xsrc[e] = a.X + (size_t)min(8 * f + (lane >> 3), a.Bsz - 1) * a.ldx + (size_t)kt0 * 64 + 8 * ((lane & 7) ^ (lane >> 3));
+  }
+  const bf16* wsrc = a.W + ((size_t)my0 * (a.K >> 5) + (size_t)kt0 * 2) * 512 + lane * 8;  // + j*(K/32)*512 + t*1024 + h*512
+  const size_t wtile = (size_t)(a.K >> 5) * 512;
+  const int n_dma = (XFR > w ? (XFR - w + WAVES - 1) / WAVES : 0) + 2 * mine;  // DMA instructions of this wave per stage
+
+  auto issue = [&](int t) {
+    char* st = smem + (t % NSTAGE) * STAGE;
+#pragma unroll
+    for (int e = 0; e < XPW; ++e)
+      if (w + WAVES * e < XFR)
+        __builtin_amdgcn_global_load_lds((const void*)(xsrc[e] + t * 64), LDS_PTR(st + (w + WAVES * e) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+      if (j < mine) {
+        const bf16* s = wsrc + j * wtile + (size_t)t * 1024;
+        char* d = st + XBYTES + (w * NTW + j) * 2048;
+        __builtin_amdgcn_global_load_lds((const void*)s, LDS_PTR(d), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(s + 512), LDS_PTR(d + 1024), 16, 0, 0);
+      }
+  };
+
+  f32x4 acc[NTW][MT];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  for (int t = 0; t < nk; ++t) {
+    wait_dma(t + 1 < nk ? n_dma : 0);     // K tile t of this wave has landed; t+1 may still fly
+    __builtin_amdgcn_s_barrier();         // ... of every wave; and every wave is done reading K tile t-1
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nk) issue(t + 2);         // into the slot K tile t-1 occupied
+    const char* st = smem + (t % NSTAGE) * STAGE;
+    bf16x8 xf[MT][2], wf[NTW][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) xf[i][h] = *(const bf16x8*)(st + (16 * i + c) * 128 + (((4 * h + q) ^ (c & 7)) << 4));
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wf[j][h] = *(const bf16x8*)(st + XBYTES + (w * NTW + j) * 2048 + h * 1024 + lane * 16);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+      if (j < mine) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][h], xf[i][h], acc[j][i], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue: lane (c,q): acc[j][i][r] = out[16 i + c][16 (my0 + j) + 4 q + r]
+  if constexpr (EPI == EPI_SWIGLU && NTW == 1) {
+    // gate tile in the even wave, up tile in the odd one: the up accumulators cross through the (now idle) ring
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the last K tile
+    float* xch = (float*)smem + (w >> 1) * (MT * 256);
+    if (w & 1) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) *(f32x4*)(xch + (i * 64 + lane) * 4) = acc[0][i];
+    }
+    __builtin_amdgcn_s_barrier();
+    if (!(w & 1) && mine > 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = 16 * i + c;
+        const f32x4 up = *(const f32x4*)(xch + (i * 64 + lane) * 4);
+        if (m < a.Bsz) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(act_silu(rbf(acc[0][i][r]))) * rbf(up[r]));
+          *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + 8 * my0 + 4 * q) = o;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = 16 * i + c;
+    if (m >= a.Bsz) continue;
+    if constexpr (EPI == EPI_SWIGLU) {
+#pragma unroll
+      for (int j = 0; j + 1 < NTW; j += 2)
+        if (j < mine) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(act_silu(rbf(acc[j][i][r]))) * rbf(acc[j + 1][i][r]));
+          *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + 8 * (my0 + j) + 4 * q) = o;
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+        if (j < mine) {
+          const int n = 16 * (my0 + j) + 4 * q;
+          if constexpr (EPI == EPI_PARTIAL) {
+            *(f32x4*)((float*)a.out + ((size_t)blockIdx.y * a.Bsz + m) * a.ldo + n) = acc[j][i];
+          } else {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r];
+            if (a.bias) {
+              const bf16x4 bb = *(const bf16x4*)(a.bias + n);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(bb[r]);
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+            *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + n) = o;
+          }
+        }
+    }
+  }
+}
+
+template <int MT, int EPI>
+void launch_one(const StreamArgs& a, dim3 grid, hipStream_t st) {
+  constexpr int WAVES = 16;
+  constexpr int LDS = NSTAGE * (2 * MT * 1024 + WBYTES);
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<MT, EPI, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    done = true;
+  }
+  hipLaunchKernelGGL((gemm_stream_kernel<MT, EPI, WAVES>), grid, dim3(64 * WAVES), LDS, st, a);
+}
+
+template <int MT>
+int launch_mt(const StreamArgs& a, int epi, dim3 grid, hipStream_t st) {
+  switch (epi) {
+    case EPI_LINEAR: launch_one<MT, EPI_LINEAR>(a, grid, st); break;
+    case EPI_SWIGLU: launch_one<MT, EPI_SWIGLU>(a, grid, st); break;
+    case EPI_PARTIAL: launch_one<MT, EPI_PARTIAL>(a, grid, st); break;
+    default: return HWOCR_EINVAL;
+  }
+  return hwocr_launch_status();
+}
+
+}  // namespace
+
+// Shapes this kernel takes: fragment-tiled W, Bsz <= 128, K % 64 == 0, every K slice non-empty.
+int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
+  if (a.Bsz < 1 || a.Bsz > 128 || (a.K % 64) || (a.N % 16) || splitk < 1) return HWOCR_EINVAL;
+  const int ktiles = a.K / 64;
+  a.ktiles_per_slice = (ktiles + splitk - 1) / splitk;
+  if ((splitk - 1) * a.ktiles_per_slice >= ktiles) return HWOCR_EINVAL;  // an empty slice would leave its slab unwritten
+  const int unit = epi == EPI_SWIGLU ? 2 : 1;
+  const int units = a.N / 16 / unit, per_wg = WG_TILES / unit;
+  // one workgroup per CU: as many tile groups as fill the chip once with this split (more only if a group would exceed
+  // 16 tiles; then whole rounds of 256 workgroups)
+  int groups = (units + per_wg - 1) / per_wg;
+  const int want = 256 / splitk;
+  if (groups < want) groups = want;
+  else if (groups * splitk > 256) groups = ((groups * splitk + 255) / 256 * 256) / splitk;
+  if (groups > units) groups = units;
+  // the balanced split must not hand any group more than per_wg units
+  while ((units + groups - 1) / groups > per_wg) ++groups;
+  const dim3 grid(groups, splitk);
+  const int mt = (a.Bsz + 15) / 16;
+  if (mt <= 1) return launch_mt<1>(a, epi, grid, stream);
+  if (mt <= 2) return launch_mt<2>(a, epi, grid, stream);
+  if (mt <= 4) return launch_mt<4>(a, epi, grid, stream);
+  return launch_mt<8>(a, epi, grid, stream);
+}

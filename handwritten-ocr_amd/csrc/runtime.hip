@@ -32,6 +32,17 @@ inline int pick_splitk(int K, int N, int want_wgs) {
   s = (chunks + per - 1) / per;
   return s;
 }
+// gemm_stream (<= 128 reads, tiled weights) fills the chip by itself; K is split to cut the activation re-staging
+// (x bytes into the CUs = 64 KiB x K / splitk against 1 KiB x N x splitk of slab): measured best 8 slabs, 12 for the
+// long-K / narrow-N down projection (tools/bench_decode_gemm.py sweep), never fewer than 2 K tiles per slice
+inline int pick_splitk_stream(int K, int N) {
+  const int ktiles = K / 64;
+  int s = K >= 4 * N ? 12 : 8;
+  if (s > ktiles / 2) s = ktiles / 2;
+  if (s < 1) s = 1;
+  const int per = (ktiles + s - 1) / s;  // every slice must own at least one K tile
+  return (ktiles + per - 1) / per;
+}
 }  // namespace
 
 extern "C" int hwocr_abi_version(void) { return 2; }
@@ -151,7 +162,11 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   const int Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
   const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
   const float scale = 1.0f / sqrtf((float)HD);
-  const int s_qkv = pick_splitk(Hd, QW, 400), s_o = pick_splitk(OW, Hd, 400), s_d = pick_splitk(m->inter, Hd, 400);
+  bool stream = nseq <= 128 && (Hd % 64) == 0 && (OW % 64) == 0 && (m->inter % 64) == 0;
+  for (int l = 0; l < m->layers && stream; ++l) stream = m->L[l].qkv_wt && m->L[l].o_wt && m->L[l].down_wt;
+  const int s_qkv = stream ? pick_splitk_stream(Hd, QW) : pick_splitk(Hd, QW, 400);
+  const int s_o = stream ? pick_splitk_stream(OW, Hd) : pick_splitk(OW, Hd, 400);
+  const int s_d = stream ? pick_splitk_stream(m->inter, Hd) : pick_splitk(m->inter, Hd, 400);
   CHECK(hwocr_embed_splice(gs->cur_ids, nullptr, m->embed, nullptr, ws->h, nseq, Hd, 1.0f, st));
   CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->L[0].in_norm_w, ws->hn, Hd, nullptr, nseq, Hd,
                           m->eps, 0, st));
