@@ -439,9 +439,115 @@ def make_model(family: str = "qwen2_vl") -> None:
         os.chmod(os.path.join(GOLD, fn), 0o644)
 
 
+# PaliGemma (BASELINE config 4): SigLIP head_dim 72 and Gemma head_dim 256 as in the 3B checkpoint, everything else tiny
+TINYPG = dict(
+    vision=dict(hidden_size=144, intermediate_size=160, num_hidden_layers=2, num_attention_heads=2, image_size=56,
+                patch_size=14, projection_dim=256, vision_use_head=False, num_image_tokens=16),
+    text=dict(model_type="gemma", vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+              num_attention_heads=2, num_key_value_heads=1, head_dim=256, max_position_embeddings=1024,
+              hidden_act="gelu_pytorch_tanh"),
+    image_token_id=500, eos=1, pad=0)
+
+
+def make_model_paligemma() -> None:
+    from safetensors.torch import save_file
+    from transformers import PaliGemmaConfig, PaliGemmaForConditionalGeneration
+    from transformers.models.siglip import SiglipImageProcessorPil
+    from PIL import Image
+    import tempfile
+
+    spec = TINYPG
+    S = spec["vision"]["image_size"]
+    proc = SiglipImageProcessorPil(size={"height": S, "width": S}, resample=3, do_rescale=True, do_normalize=True,
+                                   image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5])
+    meta = {"config": spec, "cases": {}, "family": "paligemma",
+            "source": "transformers PaliGemmaForConditionalGeneration, random init (seeded), greedy, token_type_ids == 0 "
+                      "(bidirectional image+prompt prefix), min_new_tokens == max_new_tokens"}
+    N_NEW = 16
+    weights_saved = False
+    for dtype, tag in [(torch.float32, "fp32"), (torch.bfloat16, "bf16")]:
+        cfg = PaliGemmaConfig(vision_config=dict(spec["vision"]), text_config=dict(spec["text"]),
+                              image_token_id=spec["image_token_id"], projection_dim=256, hidden_size=256, vocab_size=512,
+                              pad_token_id=spec["pad"], bos_token_id=2, eos_token_id=spec["eos"])
+        torch.manual_seed(0)
+        model = PaliGemmaForConditionalGeneration(cfg).eval()
+        g = torch.Generator().manual_seed(20260505)
+        with torch.no_grad():
+            for name, prm in sorted(model.named_parameters()):
+                if "layernorm.weight" in name and "language_model" in name or name.endswith("language_model.norm.weight"):
+                    v = 0.1 * torch.randn(prm.shape, generator=g)          # Gemma norms multiply by (1 + w)
+                elif "layer_norm" in name and name.endswith("weight") or "post_layernorm.weight" in name:
+                    v = 1.0 + 0.1 * torch.randn(prm.shape, generator=g)
+                elif name.endswith(".bias"):
+                    v = 0.05 * torch.randn(prm.shape, generator=g)
+                elif "embed_tokens" in name or "position_embedding" in name:
+                    v = 0.08 * torch.randn(prm.shape, generator=g)
+                else:
+                    v = torch.randn(prm.shape, generator=g) * (1.2 / (prm.shape[-1] if prm.dim() < 3 else prm[0].numel()) ** 0.5)
+                prm.copy_(v.to(torch.bfloat16).to(prm.dtype))
+        model.tie_weights()
+        if dtype != torch.float32:  # load like the reference does: bf16 parameters, fp32 rotary buffers
+            with tempfile.TemporaryDirectory() as tmp:
+                model.save_pretrained(tmp)
+                model = PaliGemmaForConditionalGeneration.from_pretrained(tmp, dtype=dtype).eval()
+            assert model.model.language_model.rotary_emb.inv_freq.dtype == torch.float32
+        model.generation_config.eos_token_id = spec["eos"]
+        model.generation_config.pad_token_id = spec["pad"]
+        if not weights_saved:
+            sd = {k: v.to(torch.bfloat16).contiguous() for k, v in model.state_dict().items() if k != "lm_head.weight"}
+            save_file(sd, os.path.join(GOLD, "paligemma_tiny_weights.safetensors"))
+            weights_saved = True
+        tensors = {}
+        for cname, seed, (h, w) in [("a", 21, (60, 90)), ("b", 22, (150, 200))]:
+            page = make_page(seed, h, w)
+            pv = proc(images=[Image.fromarray(page, "RGB")], return_tensors="pt")["pixel_values"]
+            n_img = (S // spec["vision"]["patch_size"]) ** 2
+            crng = np.random.default_rng(2000 + seed)
+            ids = [spec["image_token_id"]] * n_img + [2] + crng.integers(3, 490, size=7).tolist()
+            input_ids = torch.tensor([ids])
+            tt = torch.zeros_like(input_ids)
+            acts = {}
+
+            def hook(name):
+                def fn(mod, inp, outp):
+                    acts[name] = (outp[0] if isinstance(outp, tuple) else outp).detach().clone()
+                return fn
+
+            vis = model.model.vision_tower
+            hs = [vis.embeddings.register_forward_hook(hook("patch_embed")),
+                  vis.encoder.layers[0].register_forward_hook(hook("vit_block0")),
+                  vis.post_layernorm.register_forward_hook(hook("vit_last")),
+                  model.model.multi_modal_projector.register_forward_hook(hook("projector")),
+                  model.model.language_model.layers[0].register_forward_hook(hook("dec_layer0"))]
+            with torch.no_grad():
+                fw = model(input_ids=input_ids, pixel_values=pv.to(dtype), token_type_ids=tt,
+                           attention_mask=torch.ones_like(input_ids))
+            for hdl in hs:
+                hdl.remove()
+            with torch.no_grad():
+                gen = model.generate(input_ids=input_ids, pixel_values=pv.to(dtype), token_type_ids=tt,
+                                     attention_mask=torch.ones_like(input_ids), do_sample=False, max_new_tokens=N_NEW,
+                                     min_new_tokens=N_NEW, output_logits=True, return_dict_in_generate=True)
+            tensors[f"{cname}.page"] = torch.from_numpy(page.copy())
+            tensors[f"{cname}.pixel_values"] = pv[0].contiguous()
+            tensors[f"{cname}.input_ids"] = input_ids[0].to(torch.int32)
+            tensors[f"{cname}.prefill_logits"] = fw.logits[0].contiguous()
+            tensors[f"{cname}.greedy_tokens"] = gen.sequences[0, input_ids.shape[1]:].to(torch.int32)
+            tensors[f"{cname}.step_logits"] = torch.stack([l[0] for l in gen.logits]).contiguous()
+            for k, v in acts.items():
+                tensors[f"{cname}.{k}"] = (v[0] if v.dim() == 3 else v).contiguous()
+            meta["cases"][cname] = {"page_seed": seed, "page_hw": [h, w], "n_new": N_NEW, "T": len(ids)}
+        save_file(tensors, os.path.join(GOLD, f"paligemma_tiny_{tag}.safetensors"))
+        print(f"paligemma_tiny_{tag}.safetensors:", {k: tuple(v.shape) for k, v in tensors.items() if k.startswith("a.")})
+    with open(os.path.join(GOLD, "paligemma_tiny.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    for fn in os.listdir(GOLD):
+        os.chmod(os.path.join(GOLD, fn), 0o644)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="text,preprocess,nodes,image,model,model25")
+    ap.add_argument("--only", default="text,preprocess,nodes,image,model,model25,paligemma")
     only = set(ap.parse_args().only.split(","))
     os.makedirs(GOLD, exist_ok=True)
     if only & {"text", "preprocess"}:
@@ -458,6 +564,8 @@ def main() -> None:
         make_model("qwen2_vl")
     if "model25" in only:
         make_model("qwen2_5_vl")
+    if "paligemma" in only:
+        make_model_paligemma()
 
 
 if __name__ == "__main__":
