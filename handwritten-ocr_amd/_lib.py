@@ -38,10 +38,11 @@ class VitBlock(C.Structure):
 
 class Vit(C.Structure):
     _fields_ = [(n, I) for n in ("depth", "dim", "heads", "mlp_dim", "patch", "merge", "tps", "kpad", "out_dim",
-                                 "kind")] + [
+                                 "kind", "head_pad")] + [
         ("eps", F), ("patch_w", P), ("blocks", C.POINTER(VitBlock)),
         ("merger_ln_w", P), ("merger_ln_b", P), ("merger_fc1_w", P), ("merger_fc1_b", P),
-        ("merger_fc2_w", P), ("merger_fc2_b", P), ("rope_cos", P), ("rope_sin", P), ("pixel_lut", P)]
+        ("merger_fc2_w", P), ("merger_fc2_b", P), ("rope_cos", P), ("rope_sin", P), ("pixel_lut", P), ("patch_b", P),
+        ("pos_embed", P)]
 
 
 class VitLayout(C.Structure):
@@ -59,8 +60,9 @@ class DecLayer(C.Structure):
 
 
 class Decoder(C.Structure):
-    _fields_ = [(n, I) for n in ("layers", "hidden", "Hq", "Hkv", "inter", "vocab", "sec0", "sec1")] + [
-        ("eps", F), ("embed", P), ("lm_head", P), ("lm_head_t", P), ("final_norm_w", P), ("L", C.POINTER(DecLayer)),
+    _fields_ = [(n, I) for n in ("layers", "hidden", "Hq", "Hkv", "inter", "vocab", "sec0", "sec1", "head_dim",
+                                 "gemma")] + [
+        ("eps", F), ("embed_scale", F), ("embed", P), ("lm_head", P), ("lm_head_t", P), ("final_norm_w", P), ("L", C.POINTER(DecLayer)),
         ("rope_cos", P), ("rope_sin", P)]
 
 
@@ -84,14 +86,14 @@ _HIP_SIGS = {
     "hwocr_gemm_skinny": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "hwocr_tile_weights": ([P, P, I, I, I, P], I),
     "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, I, P], I),
-    "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, P], I),
+    "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, P], I),
     "hwocr_attn_varlen": ([P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, F, P], I),
     "hwocr_patchify": ([P, P, P, I, I, I, I, I, I, I, I, P, P], I),
     "hwocr_layernorm": ([P, P, P, P, I, I, I, I, F, P], I),
     "hwocr_add_rmsnorm": ([P, I, L, I, P, P, I, P, P, I, P, I, I, F, I, P], I),
     "hwocr_vit_rope_split": ([P, P, P, P, P, P, P, P, I, I, I, I, P], I),
-    "hwocr_mrope_kv_prefill": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, I, P], I),
-    "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, I, P], I),
+    "hwocr_mrope_kv_prefill": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, I, I, P], I),
+    "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, I, I, P], I),
     "hwocr_embed_splice": ([P, P, P, P, P, I, I, F, P], I),
     "hwocr_argmax_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P], I),
     "hwocr_vit_forward": ([C.POINTER(Vit), C.POINTER(VitWs), P, I, I, I, I, C.POINTER(VitLayout), P, P], I),

@@ -37,7 +37,7 @@ __device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
 }
 
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(PrefillArgs a) {
+__global__ __launch_bounds__(256, HD > 128 ? 1 : 2) void attn_prefill_kernel(PrefillArgs a) {
   constexpr int HDP = (HD + 31) / 32 * 32;  // d rows of the V^T tile, padded to whole 32-row MFMA tiles
   constexpr int KS = HD * 2 + 16;           // K tile row stride (bytes): +1 slot -> conflict-free ds_read_b128
   constexpr int VS = 144;                   // V^T tile row stride (bytes): 64 keys + 16 B -> conflict-free ds_read_b128
@@ -461,16 +461,19 @@ struct DecodeArgs {
   int kv_tiled;
 };
 
-constexpr int DEC_HD = 128;
 
 // Keys are walked in blocks of 32.  MFMA tile rows are assigned to keys so that the score registers a lane ends up with
 // are 8 CONSECUTIVE keys (tile t, row 4a+r <-> key 8a + 4t + r): packed to bf16 they are the B operand of the PV product
 // in natural k order, and the matching A operand is one 16-byte load of a V^T row.
 // WAVES = 4: keys also split over `nsplit` workgroups (few reads in flight), partials merged by attn_decode_merge_kernel;
 // WAVES = 8: one workgroup per (read, kv head) walks the whole cache and writes the final output - no merge launch.
-template <bool TILED, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 3) void attn_decode_kernel(DecodeArgs a) {
-  __shared__ float s_o[WAVES][DEC_HD][16];
+// DEC_HD: 128, or 256 (Gemma; row layout only, 4 waves: the merge buffer is WAVES x DEC_HD x 16 floats).
+template <bool TILED, int WAVES, int DEC_HD>
+__global__ __launch_bounds__(64 * WAVES, DEC_HD == 256 ? 1 : (WAVES == 8 ? 2 : 3)) void attn_decode_kernel(DecodeArgs a) {
+  constexpr int KS = DEC_HD / 32, VD = DEC_HD / 16;  // k-steps of the score product, d-tiles of the PV product
+  static_assert(!TILED || DEC_HD == 128, "the fragment-tiled cache layout is defined for head_dim 128");
+  constexpr int QC = DEC_HD == 256 ? 8 : 16;  // query columns kept for the merge (64 KB static LDS limit): G <= QC
+  __shared__ float s_o[WAVES][DEC_HD][QC];
   __shared__ float s_m[WAVES][16];
   __shared__ float s_l[WAVES][16];
   const int split = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
@@ -480,9 +483,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 3) void attn_decode_ke
   const bf16* Kp = a.K + b * a.k_seq + hk * a.k_head;
   const bf16* Vp = a.VT + b * a.v_seq + hk * a.v_head;
 
-  bf16x8 qf[4];
+  bf16x8 qf[KS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < KS; ++s) {
     if (c < a.G)
       qf[s] = *(const bf16x8*)(a.Q + ((long)b * a.Hq + hk * a.G + c) * DEC_HD + 32 * s + 8 * qd);
     else
@@ -490,38 +493,38 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 3) void attn_decode_ke
       for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)0.0f;
   }
 
-  f32x4 o[8];
+  f32x4 o[VD];
 #pragma unroll
-  for (int d = 0; d < 8; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int d = 0; d < VD; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = NEG_BIG, l = 0.f;
 
   const int krow = 8 * (c >> 2) + (c & 3);  // key (within the block) of tile-0 row c; tile 1: +4
   const int nblk = (len + 31) >> 5;
   for (int kb = split * WAVES + w; kb < nblk; kb += a.nsplit * WAVES) {
     const int k0 = kb * 32;
-    bf16x8 kf[2][4], vt[8];
+    bf16x8 kf[2][KS], vt[VD];
     if constexpr (TILED) {  // one contiguous KiB per fragment, the cache is stored in operand order
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < KS; ++s)
           kf[t][s] = __builtin_nontemporal_load((const bf16x8*)(Kp + ((((long)kb * 2 + t) * 4 + s) * 64 + lane) * 8));
 #pragma unroll
-      for (int d = 0; d < 8; ++d)
+      for (int d = 0; d < VD; ++d)
         vt[d] = __builtin_nontemporal_load((const bf16x8*)(Vp + (((long)kb * 8 + d) * 64 + lane) * 8));
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const bf16* kr = Kp + (long)min(k0 + krow + 4 * t, len - 1) * DEC_HD + 8 * qd;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) kf[t][s] = *(const bf16x8*)(kr + 32 * s);
+        for (int s = 0; s < KS; ++s) kf[t][s] = *(const bf16x8*)(kr + 32 * s);
       }
 #pragma unroll
-      for (int d = 0; d < 8; ++d) vt[d] = *(const bf16x8*)(Vp + (long)(16 * d + c) * a.v_row + k0 + 8 * qd);
+      for (int d = 0; d < VD; ++d) vt[d] = *(const bf16x8*)(Vp + (long)(16 * d + c) * a.v_row + k0 + 8 * qd);
     }
     if (k0 + 32 > len) {  // tail block: keys past the end carry p = 0, keep 0 * x finite
 #pragma unroll
-      for (int d = 0; d < 8; ++d)
+      for (int d = 0; d < VD; ++d)
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (k0 + 8 * qd + e >= len) vt[d][e] = (bf16)0.0f;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 3) void attn_decode_ke
     for (int t = 0; t < 2; ++t) {
       sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][s], qf[s], sc[t], 0, 0, 0);
+      for (int s = 0; s < KS; ++s) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][s], qf[s], sc[t], 0, 0, 0);
     }
     float mx = NEG_BIG;
 #pragma unroll
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 3) void attn_decode_ke
     l = l * alpha + rs;
     m = m_new;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
+    for (int d = 0; d < VD; ++d) {
       o[d] *= alpha;
       o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[d], pb, o[d], 0, 0, 0);
     }
@@ -571,9 +574,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 3) void attn_decode_ke
 
   // ---- merge the 4 waves through LDS; o[d][e] = O^T[16d + 4qd + e][query c]
 #pragma unroll
-  for (int d = 0; d < 8; ++d)
+  for (int d = 0; d < VD; ++d)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s_o[w][16 * d + 4 * qd + e][c] = o[d][e];
+    for (int e = 0; e < 4; ++e)
+      if (c < QC) s_o[w][16 * d + 4 * qd + e][c] = o[d][e];
   if (qd == 0) { s_m[w][c] = m; s_l[w][c] = l; }
   __syncthreads();
   for (int idx = tid; idx < a.G * DEC_HD; idx += 64 * WAVES) {
@@ -598,6 +602,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 3) void attn_decode_ke
   }
 }
 
+template <int DEC_HD>
 __global__ __launch_bounds__(256) void attn_decode_merge_kernel(DecodeArgs a) {
   const int hk = blockIdx.x, b = blockIdx.y;
   for (int idx = threadIdx.x; idx < a.G * DEC_HD; idx += 256) {
@@ -640,6 +645,8 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
                                     : launch_prefill<80, false>(a, nseg, heads, max_len, stream);
   if (head_dim == 128) return causal ? launch_prefill<128, true>(a, nseg, heads, max_len, stream)
                                      : launch_prefill<128, false>(a, nseg, heads, max_len, stream);
+  if (head_dim == 256) return causal ? launch_prefill<256, true>(a, nseg, heads, max_len, stream)
+                                     : launch_prefill<256, false>(a, nseg, heads, max_len, stream);
   if (head_dim == 64) return causal ? launch_prefill<64, true>(a, nseg, heads, max_len, stream)
                                     : launch_prefill<64, false>(a, nseg, heads, max_len, stream);
   if (head_dim == 32) return causal ? launch_prefill<32, true>(a, nseg, heads, max_len, stream)
@@ -670,21 +677,28 @@ extern "C" int hwocr_attn_varlen(const void* Q, const void* K, const void* VT, v
 extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out,
                                  float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit,
                                  long k_seq, long k_head, long v_seq, long v_head, long v_row, float scale,
-                                 int kv_tiled, hipStream_t stream) {
+                                 int head_dim, int kv_tiled, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseq <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16 || nsplit < 1) return HWOCR_EINVAL;
   if (nsplit > 1 && (!part_o || !part_ml)) return HWOCR_EINVAL;
   if ((v_row % 64) || (k_seq % 8) || (k_head % 8) || (v_seq % 8) || (v_head % 8)) return HWOCR_EINVAL;
+  if ((head_dim != 128 && head_dim != 256) || (kv_tiled && head_dim != 128)) return HWOCR_EINVAL;
+  if (head_dim == 256 && Hq / Hkv > 8) return HWOCR_EINVAL;
   DecodeArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, lens, part_o, part_ml, (bf16*)out,
                k_seq, k_head, v_seq, v_head, v_row, Hq, Hkv, Hq / Hkv, nsplit, scale * 1.4426950408889634f, kv_tiled};
-  if (nsplit == 1) {
-    if (kv_tiled) hipLaunchKernelGGL((attn_decode_kernel<true, 8>), dim3(1, Hkv, nseq), dim3(512), 0, stream, a);
-    else hipLaunchKernelGGL((attn_decode_kernel<false, 8>), dim3(1, Hkv, nseq), dim3(512), 0, stream, a);
-  } else if (kv_tiled) {
-    hipLaunchKernelGGL((attn_decode_kernel<true, 4>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
-  } else {
-    hipLaunchKernelGGL((attn_decode_kernel<false, 4>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+  if (head_dim == 256) {  // 4 waves; a single pass when the caller asks for no split
+    hipLaunchKernelGGL((attn_decode_kernel<false, 4, 256>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+    if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<256>, dim3(Hkv, nseq), dim3(256), 0, stream, a);
+    return hwocr_launch_status();
   }
-  if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(Hkv, nseq), dim3(256), 0, stream, a);
+  if (nsplit == 1) {
+    if (kv_tiled) hipLaunchKernelGGL((attn_decode_kernel<true, 8, 128>), dim3(1, Hkv, nseq), dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<false, 8, 128>), dim3(1, Hkv, nseq), dim3(512), 0, stream, a);
+  } else if (kv_tiled) {
+    hipLaunchKernelGGL((attn_decode_kernel<true, 4, 128>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((attn_decode_kernel<false, 4, 128>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+  }
+  if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<128>, dim3(Hkv, nseq), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }

@@ -314,51 +314,55 @@ struct MropeArgs {
   long k_seq, k_head, v_seq, v_head, v_row;
   int tiled;
 };
-constexpr int DHD = 128;
-
+// DHD: decoder head_dim, 128 (Qwen families) or 256 (Gemma).  The rope tables are [maxpos][DHD/2]; with sec0 >= DHD/2 every
+// frequency takes the first position axis, i.e. plain 1-D RoPE (HF gemma/modeling_gemma.py:166-190: the same bf16 chain).
+template <int DHD>
 __device__ __forceinline__ void mrope_pair(const bf16x8 va, const bf16x8 vb, int d0, const int pt, const int ph,
                                            const int pw, const MropeArgs& a, bf16x8& oa, bf16x8& ob) {
+  constexpr int HALF = DHD / 2;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int i = d0 + e;  // 0..63
+    const int i = d0 + e;  // 0..HALF-1
     const int p = i < a.sec0 ? pt : (i < a.sec1 ? ph : pw);
-    const float cs = bf2f(a.cos_tab[p * 64 + i]), sn = bf2f(a.sin_tab[p * 64 + i]);
+    const float cs = bf2f(a.cos_tab[p * HALF + i]), sn = bf2f(a.sin_tab[p * HALF + i]);
     const float x1 = bf2f(va[e]), x2 = bf2f(vb[e]);
     oa[e] = f2bf(rbf(x1 * cs) + rbf(-x2 * sn));
     ob[e] = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
   }
 }
 
+template <int DHD>
 __global__ __launch_bounds__(256) void mrope_kv_prefill_kernel(MropeArgs a) {
+  constexpr int HALF = DHD / 2, HC = HALF / 8;  // 16-byte chunks per half head
   __shared__ bf16 s_v[64][DHD + 2];
   const int r0 = blockIdx.x * 64, hy = blockIdx.y, tid = threadIdx.x;
   const int W = (a.Hq + 2 * a.Hkv) * DHD;
   if (hy < a.Hq + a.Hkv) {
     const bool isk = hy >= a.Hq;
     const int col0 = isk ? a.Hq * DHD + (hy - a.Hq) * DHD : hy * DHD;
-    for (int id = tid; id < 64 * 8; id += 256) {
-      const int rr = id >> 3, j = id & 7;
+    for (int id = tid; id < 64 * HC; id += 256) {
+      const int rr = id / HC, j = id % HC;
       const int row = r0 + rr;
       if (row >= a.rows) continue;
       const bf16* src = a.qkv + (long)row * W + col0 + 8 * j;
       bf16x8 oa, ob;
-      mrope_pair(*(const bf16x8*)src, *(const bf16x8*)(src + 64), 8 * j, a.pos[row], a.pos[a.rows + row],
-                 a.pos[2 * a.rows + row], a, oa, ob);
+      mrope_pair<DHD>(*(const bf16x8*)src, *(const bf16x8*)(src + HALF), 8 * j, a.pos[row], a.pos[a.rows + row],
+                      a.pos[2 * a.rows + row], a, oa, ob);
       const int sq = row / a.rows_per_seq, slot = row % a.rows_per_seq;
       if (isk) {
         bf16* kb = a.K + sq * a.k_seq + (hy - a.Hq) * a.k_head;
         *(bf16x8*)(kb + (a.tiled ? kv_tiled_k(slot, 8 * j) : (long)slot * DHD + 8 * j)) = oa;
-        *(bf16x8*)(kb + (a.tiled ? kv_tiled_k(slot, 64 + 8 * j) : (long)slot * DHD + 64 + 8 * j)) = ob;
+        *(bf16x8*)(kb + (a.tiled ? kv_tiled_k(slot, HALF + 8 * j) : (long)slot * DHD + HALF + 8 * j)) = ob;
       } else {
         bf16* dst = a.Q + (long)row * a.Hq * DHD + hy * DHD + 8 * j;
         *(bf16x8*)dst = oa;
-        *(bf16x8*)(dst + 64) = ob;
+        *(bf16x8*)(dst + HALF) = ob;
       }
     }
   } else {
     const int hk = hy - a.Hq - a.Hkv;
-    for (int id = tid; id < 64 * 16; id += 256) {
-      const int rr = id >> 4, j = id & 15;
+    for (int id = tid; id < 64 * (DHD / 8); id += 256) {
+      const int rr = id / (DHD / 8), j = id % (DHD / 8);
       const int row = r0 + rr;
       if (row >= a.rows) continue;
       const bf16x8 v = *(const bf16x8*)(a.qkv + (long)row * W + (a.Hq + a.Hkv + hk) * DHD + 8 * j);
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256) void mrope_kv_prefill_kernel(MropeArgs a) {
     if (row < a.rows) {
       const int slot = row % a.rows_per_seq;
       bf16* vb = a.VT + (row / a.rows_per_seq) * a.v_seq + hk * a.v_head;
-      for (int d = dg * 32; d < dg * 32 + 32; ++d)
+      for (int d = dg * (DHD / 4); d < (dg + 1) * (DHD / 4); ++d)
         vb[a.tiled ? kv_tiled_v(d, slot) : (long)d * a.v_row + slot] = s_v[rr][d];
     }
   }
@@ -386,9 +390,11 @@ struct DecQkvArgs {
   const bf16* cos_tab; const bf16* sin_tab;
   int Hq, Hkv; long k_seq, k_head, v_seq, v_head, v_row; int tiled;
 };
+template <int DHD>
 __global__ __launch_bounds__(256) void decode_qkv_finish_kernel(DecQkvArgs a) {
+  constexpr int HALF = DHD / 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16* row = (bf16*)smem;  // [(Hq+2Hkv)*128]
+  bf16* row = (bf16*)smem;  // [(Hq+2Hkv)*DHD]
   const int b = blockIdx.x, tid = threadIdx.x;
   const int W = (a.Hq + 2 * a.Hkv) * DHD;
   for (int ch = tid; ch < W / 8; ch += 256) {
@@ -411,22 +417,22 @@ __global__ __launch_bounds__(256) void decode_qkv_finish_kernel(DecQkvArgs a) {
   }
   __syncthreads();
   const int slot = a.lens[b] - 1;
-  const int p = slot + a.rope_delta[b];  // all three M-RoPE axes coincide on generated tokens
-  // q and k heads: pairs (d, d+64)
-  for (int id = tid; id < (a.Hq + a.Hkv) * 64; id += 256) {
-    const int hy = id >> 6, i = id & 63;
-    const float cs = bf2f(a.cos_tab[p * 64 + i]), sn = bf2f(a.sin_tab[p * 64 + i]);
-    const float x1 = bf2f(row[hy * DHD + i]), x2 = bf2f(row[hy * DHD + 64 + i]);
+  const int p = slot + a.rope_delta[b];  // all position axes coincide on generated tokens
+  // q and k heads: pairs (d, d + DHD/2)
+  for (int id = tid; id < (a.Hq + a.Hkv) * HALF; id += 256) {
+    const int hy = id / HALF, i = id % HALF;
+    const float cs = bf2f(a.cos_tab[p * HALF + i]), sn = bf2f(a.sin_tab[p * HALF + i]);
+    const float x1 = bf2f(row[hy * DHD + i]), x2 = bf2f(row[hy * DHD + HALF + i]);
     const bf16 oa = f2bf(rbf(x1 * cs) + rbf(-x2 * sn));
     const bf16 ob = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
     if (hy < a.Hq) {
       bf16* dst = a.Q + ((long)b * a.Hq + hy) * DHD;
       dst[i] = oa;
-      dst[64 + i] = ob;
+      dst[HALF + i] = ob;
     } else {
       bf16* kb = a.K + b * a.k_seq + (hy - a.Hq) * a.k_head;
       kb[a.tiled ? kv_tiled_k(slot, i) : (long)slot * DHD + i] = oa;
-      kb[a.tiled ? kv_tiled_k(slot, 64 + i) : (long)slot * DHD + 64 + i] = ob;
+      kb[a.tiled ? kv_tiled_k(slot, HALF + i) : (long)slot * DHD + HALF + i] = ob;
     }
   }
   for (int id = tid; id < a.Hkv * DHD; id += 256) {
@@ -582,26 +588,33 @@ extern "C" int hwocr_vit_rope_split(const void* qkv, void* Q, void* K, void* VT,
 extern "C" int hwocr_mrope_kv_prefill(const void* qkv, void* Q, void* K, void* VT, const int* pos,
                                       const void* cos_tab, const void* sin_tab, int rows, int rows_per_seq, int Hq,
                                       int Hkv, int sec0, int sec1, long k_seq, long k_head, long v_seq, long v_head,
-                                      long v_row, int kv_tiled, hipStream_t stream) {
+                                      long v_row, int head_dim, int kv_tiled, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (rows <= 0 || Hq <= 0 || Hkv <= 0 || rows_per_seq <= 0 || rows_per_seq > v_row) return HWOCR_EINVAL;
+  if ((head_dim != 128 && head_dim != 256) || (kv_tiled && head_dim != 128)) return HWOCR_EINVAL;
   MropeArgs a{(const bf16*)qkv, (bf16*)Q, (bf16*)K, (bf16*)VT, pos, (const bf16*)cos_tab,
               (const bf16*)sin_tab, rows, rows_per_seq, Hq, Hkv, sec0, sec1, k_seq, k_head, v_seq, v_head, v_row,
               kv_tiled};
-  hipLaunchKernelGGL(mrope_kv_prefill_kernel, dim3((rows + 63) / 64, Hq + 2 * Hkv), dim3(256), 0, stream, a);
+  if (head_dim == 128)
+    hipLaunchKernelGGL(mrope_kv_prefill_kernel<128>, dim3((rows + 63) / 64, Hq + 2 * Hkv), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(mrope_kv_prefill_kernel<256>, dim3((rows + 63) / 64, Hq + 2 * Hkv), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }
 
 extern "C" int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_stride, const void* bias, void* Q,
                                        void* K, void* VT, const int* lens, const int* rope_delta,
                                        const void* cos_tab, const void* sin_tab, int nseq, int Hq, int Hkv,
-                                       long k_seq, long k_head, long v_seq, long v_head, long v_row, int kv_tiled,
-                                       hipStream_t stream) {
+                                       long k_seq, long k_head, long v_seq, long v_head, long v_row, int head_dim,
+                                       int kv_tiled, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseq <= 0 || nslab < 1 || !slabs) return HWOCR_EINVAL;
+  if ((head_dim != 128 && head_dim != 256) || (kv_tiled && head_dim != 128)) return HWOCR_EINVAL;
   DecQkvArgs a{slabs, nslab, slab_stride, (const bf16*)bias, (bf16*)Q, (bf16*)K, (bf16*)VT, lens, rope_delta,
                (const bf16*)cos_tab, (const bf16*)sin_tab, Hq, Hkv, k_seq, k_head, v_seq, v_head, v_row, kv_tiled};
-  hipLaunchKernelGGL(decode_qkv_finish_kernel, dim3(nseq), dim3(256), (size_t)(Hq + 2 * Hkv) * DHD * 2, stream, a);
+  const size_t lds = (size_t)(Hq + 2 * Hkv) * head_dim * 2;
+  if (head_dim == 128) hipLaunchKernelGGL(decode_qkv_finish_kernel<128>, dim3(nseq), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL(decode_qkv_finish_kernel<256>, dim3(nseq), dim3(256), lds, stream, a);
   return hwocr_launch_status();
 }
 

@@ -105,9 +105,9 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(WideArgs a) {
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = m0 + wm * 64 + mt * 16 + c;
-    if constexpr (EPI == EPI_SWIGLU) {
+    if constexpr (is_glu<EPI>) {
 #pragma unroll
-      for (int nt = 0; nt < 4; nt += 2) store_swiglu(a, acc[nt][mt], acc[nt + 1][mt], m, n0 + wn * 64 + nt * 16, q);
+      for (int nt = 0; nt < 4; nt += 2) store_glu<EPI>(a, acc[nt][mt], acc[nt + 1][mt], m, n0 + wn * 64 + nt * 16, q);
     } else {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) store_tile<EPI>(a, acc[nt][mt], m, n0 + wn * 64 + nt * 16 + 4 * q);
@@ -232,15 +232,15 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_skinny_kernel(SkinnyArgs a) {
   for (int b = 0; b < NB; ++b) {
     const int m = 16 * b + c;
     if (m >= a.Bsz) continue;
-    if constexpr (EPI == EPI_SWIGLU) {
-      static_assert(EPI != EPI_SWIGLU || NT == 2, "gate/up tiles come in pairs");
+    if constexpr (is_glu<EPI>) {
+      static_assert(!is_glu<EPI> || NT == 2, "gate/up tiles come in pairs");
       if (n0 < a.N) {
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float gte = rbf(acc[0][b][r]);
           const float up = rbf(acc[NT - 1][b][r]);
-          o[r] = f2bf(rbf(act_silu(gte)) * up);
+          o[r] = f2bf(rbf(glu_gate<EPI>(gte)) * up);
         }
         *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + (n0 >> 1) + 4 * q) = o;
       }
@@ -305,6 +305,10 @@ int launch_skinny(const SkinnyArgs& a, int epi, int splitk, bool tiled, hipStrea
       if (wg4 >= 512) launch_skinny_cfg<NB, EPI_SWIGLU, 2, 4, KC>(a, splitk, tiled, st);
       else launch_skinny_cfg<NB, EPI_SWIGLU, 2, 2, KC>(a, splitk, tiled, st);
       break;
+    case EPI_GEGLU:
+      if (wg4 >= 512) launch_skinny_cfg<NB, EPI_GEGLU, 2, 4, KC>(a, splitk, tiled, st);
+      else launch_skinny_cfg<NB, EPI_GEGLU, 2, 2, KC>(a, splitk, tiled, st);
+      break;
     case EPI_PARTIAL:
       if (wg4 >= 512) launch_skinny_cfg<NB, EPI_PARTIAL, 2, 4, KC>(a, splitk, tiled, st);
       else launch_skinny_cfg<NB, EPI_PARTIAL, 1, 2, KC>(a, splitk, tiled, st);
@@ -361,7 +365,7 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 8) != 0 || (ldx % 8) || (ldw % 8) || (ldo % 4))
     return HWOCR_EINVAL;
-  if (epi == EPI_SWIGLU && (N % 32) != 0) return HWOCR_EINVAL;
+  if ((epi == EPI_SWIGLU || epi == EPI_GEGLU) && (N % 32) != 0) return HWOCR_EINVAL;
   if (epi == EPI_RESIDUAL && (!res || (ldres % 4))) return HWOCR_EINVAL;
   WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)out,
              M, N, K, ldx, ldw, ldo, ldres, (M + BM - 1) / BM, (N + BN - 1) / BN};
@@ -385,6 +389,8 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_QUICKGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
+    hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_GELU_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
+    hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
     attr_done = true;
   }
   if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
@@ -394,6 +400,8 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
     case EPI_QUICKGELU: hipLaunchKernelGGL(gemm_wide_kernel<EPI_QUICKGELU>, grid, block, WIDE_LDS, stream, a); break;
     case EPI_GELU: hipLaunchKernelGGL(gemm_wide_kernel<EPI_GELU>, grid, block, WIDE_LDS, stream, a); break;
     case EPI_SWIGLU: hipLaunchKernelGGL(gemm_wide_kernel<EPI_SWIGLU>, grid, block, WIDE_LDS, stream, a); break;
+    case EPI_GELU_TANH: hipLaunchKernelGGL(gemm_wide_kernel<EPI_GELU_TANH>, grid, block, WIDE_LDS, stream, a); break;
+    case EPI_GEGLU: hipLaunchKernelGGL(gemm_wide_kernel<EPI_GEGLU>, grid, block, WIDE_LDS, stream, a); break;
     default: return HWOCR_EINVAL;
   }
   if (prof) {
@@ -430,11 +438,11 @@ extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias,
                                  int K, int ldx, int ldw, int ldo, int epi, int splitk, int w_tiled,
                                  hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
-  if (Bsz <= 0 || Bsz > 256 || N <= 0 || K <= 0 || (K % 32) || (N % 16) || (epi == EPI_SWIGLU && (N % 32)) || (ldx % 8) || (ldw % 8) || (ldo % 4) ||
+  if (Bsz <= 0 || Bsz > 256 || N <= 0 || K <= 0 || (K % 32) || (N % 16) || ((epi == EPI_SWIGLU || epi == EPI_GEGLU) && (N % 32)) || (ldx % 8) || (ldw % 8) || (ldo % 4) ||
       splitk < 1)
     return HWOCR_EINVAL;
   if (epi != EPI_PARTIAL && splitk != 1) return HWOCR_EINVAL;
-  if (epi == EPI_SWIGLU && bias) return HWOCR_EINVAL;
+  if ((epi == EPI_SWIGLU || epi == EPI_GEGLU) && bias) return HWOCR_EINVAL;
   // up to 128 rows over fragment-tiled weights: the LDS-DMA streaming kernel (gemm_stream.hip)
   static const bool use_stream = [] { const char* e = getenv("HWOCR_GEMM_STREAM"); return !e || atoi(e) != 0; }();
   if (use_stream && w_tiled && Bsz <= 128 && (K % 64) == 0) {

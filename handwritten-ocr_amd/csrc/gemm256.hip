@@ -194,12 +194,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   }
 
   // ---- epilogue: lane (c,q) of tile (nt,mt) holds out[m0 + 128wr + 16mt + c][n0 + 64wc + 16nt + 4q .. +3]
-  if constexpr (EPI == EPI_SWIGLU) {
+  if constexpr (is_glu<EPI>) {
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
       const int m = m0 + 128 * wr + 16 * mt + c;
 #pragma unroll
-      for (int nt = 0; nt < 4; nt += 2) store_swiglu(a, acc[nt][mt], acc[nt + 1][mt], m, n0 + 64 * wc + 16 * nt, q);
+      for (int nt = 0; nt < 4; nt += 2) store_glu<EPI>(a, acc[nt][mt], acc[nt + 1][mt], m, n0 + 64 * wc + 16 * nt, q);
     }
   } else {
     // Through LDS so that HBM sees whole 128-byte rows: the fragment layout gives a lane 8 bytes of 16 different rows
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
           float v = acc[nt][mt][r] + bf2f(bv[nt][r]);
           if constexpr (EPI == EPI_QUICKGELU) v = act_quick_gelu(rbf(v));
           else if constexpr (EPI == EPI_GELU) v = act_gelu_erf(rbf(v));
+          else if constexpr (EPI == EPI_GELU_TANH) v = act_gelu_tanh(rbf(v));
           o[r] = f2bf(v);
         }
         *(bf16x4*)(ep + ml * 128 + (((2 * nt + (q >> 1)) ^ (ml & 7)) << 4) + (q & 1) * 8) = o;
@@ -278,6 +279,8 @@ int hwocr_gemm_wide256(const WideArgs& a, int epi, hipStream_t stream) {
     case EPI_QUICKGELU: launch<EPI_QUICKGELU>(a, stream); break;
     case EPI_GELU: launch<EPI_GELU>(a, stream); break;
     case EPI_SWIGLU: launch<EPI_SWIGLU>(a, stream); break;
+    case EPI_GELU_TANH: launch<EPI_GELU_TANH>(a, stream); break;
+    case EPI_GEGLU: launch<EPI_GEGLU>(a, stream); break;
     default: return HWOCR_EINVAL;
   }
   return hwocr_launch_status();

@@ -12,8 +12,11 @@ enum : int {
   EPI_QUICKGELU = HWOCR_EPI_QUICKGELU,  // x*sigmoid(1.702x), each step rounded like the bf16 module chain
   EPI_GELU = HWOCR_EPI_GELU,            // exact erf GELU of bf16(acc + bias)
   EPI_SWIGLU = HWOCR_EPI_SWIGLU,        // rows interleaved [16 gate][16 up]: bf16(bf16(silu(g)) * u)
-  EPI_PARTIAL = HWOCR_EPI_PARTIAL       // fp32 split-K slab (skinny only)
+  EPI_PARTIAL = HWOCR_EPI_PARTIAL,      // fp32 split-K slab (skinny only)
+  EPI_GELU_TANH = HWOCR_EPI_GELU_TANH,  // tanh-approximated GELU of bf16(acc + bias)
+  EPI_GEGLU = HWOCR_EPI_GEGLU           // as EPI_SWIGLU with the tanh GELU on the gate
 };
+template <int EPI> inline constexpr bool is_glu = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
 
 __device__ __forceinline__ float act_quick_gelu(float v) {
   const float t = rbf(1.702f * v);
@@ -24,6 +27,14 @@ __device__ __forceinline__ float act_gelu_erf(float v) {
   return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }
+// torch's tanh GELU: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float act_gelu_tanh(float v) {
+  return 0.5f * v * (1.0f + tanhf(0.79788456080286535588f * (v + 0.044715f * (v * v * v))));
+}
+template <int EPI> __device__ __forceinline__ float glu_gate(float g) {
+  if constexpr (EPI == EPI_GEGLU) return act_gelu_tanh(g);
+  else return act_silu(g);
+}
 
 struct WideArgs {
   const bf16* X; const bf16* W; const bf16* bias; const bf16* res; bf16* out;
@@ -33,7 +44,7 @@ struct WideArgs {
 // One 16x16 MFMA tile whose A operand was the weight tile: the lane holds out[m][n .. n+3] (4 consecutive features).
 template <int EPI>
 __device__ __forceinline__ void store_tile(const WideArgs& a, const f32x4& acc, int m, int n) {
-  static_assert(EPI != EPI_SWIGLU, "SwiGLU consumes a (gate, up) tile pair: store_swiglu");
+  static_assert(!is_glu<EPI>, "gated epilogues consume a (gate, up) tile pair: store_glu");
   if (m >= a.M || n >= a.N) return;
   float v[4];
 #pragma unroll
@@ -54,6 +65,9 @@ __device__ __forceinline__ void store_tile(const WideArgs& a, const f32x4& acc, 
   } else if constexpr (EPI == EPI_GELU) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = f2bf(act_gelu_erf(rbf(v[r])));
+  } else if constexpr (EPI == EPI_GELU_TANH) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = f2bf(act_gelu_tanh(rbf(v[r])));
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
@@ -62,7 +76,8 @@ __device__ __forceinline__ void store_tile(const WideArgs& a, const f32x4& acc, 
 }
 
 // gate tile (weight rows n_gate .. +15) and the up tile that follows it -> out[m][n_gate/2 + 4q .. +3]
-__device__ __forceinline__ void store_swiglu(const WideArgs& a, const f32x4& g, const f32x4& u, int m, int n_gate, int q) {
+template <int EPI>
+__device__ __forceinline__ void store_glu(const WideArgs& a, const f32x4& g, const f32x4& u, int m, int n_gate, int q) {
   if (m >= a.M || n_gate >= a.N) return;
   float gb[4] = {0.f, 0.f, 0.f, 0.f}, ub[4] = {0.f, 0.f, 0.f, 0.f};
   if (a.bias) {  // bias rows follow the interleaved weight rows (Qwen2.5-VL vision MLP)
@@ -72,7 +87,7 @@ __device__ __forceinline__ void store_swiglu(const WideArgs& a, const f32x4& g, 
   }
   bf16x4 o;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(act_silu(rbf(g[r] + gb[r]))) * rbf(u[r] + ub[r]));
+  for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(glu_gate<EPI>(rbf(g[r] + gb[r]))) * rbf(u[r] + ub[r]));
   *(bf16x4*)(a.out + (size_t)m * a.ldo + (n_gate >> 1) + 4 * q) = o;
 }
 

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
   const int c = lane & 15, q = lane >> 4;
 
   // ---- this workgroup's weight tiles [t0, t1) (SwiGLU: whole gate/up pairs) and K tiles [kt0, kt0 + nk)
-  constexpr int UNIT = EPI == EPI_SWIGLU ? 2 : 1;
+  constexpr int UNIT = is_glu<EPI> ? 2 : 1;
   const int units = (a.N >> 4) / UNIT;
   const int t0 = (int)((long)blockIdx.x * units / gridDim.x) * UNIT;
   const int t1 = (int)((long)(blockIdx.x + 1) * units / gridDim.x) * UNIT;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
   }
 
   // ---- epilogue: lane (c,q): acc[j][i][r] = out[16 i + c][16 (my0 + j) + 4 q + r]
-  if constexpr (EPI == EPI_SWIGLU && NTW == 1) {
+  if constexpr (is_glu<EPI> && NTW == 1) {
     // gate tile in the even wave, up tile in the odd one: the up accumulators cross through the (now idle) ring
     __builtin_amdgcn_s_barrier();  // every wave is done reading the last K tile
     float* xch = (float*)smem + (w >> 1) * (MT * 256);
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
         if (m < a.Bsz) {
           bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(act_silu(rbf(acc[0][i][r]))) * rbf(up[r]));
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(glu_gate<EPI>(rbf(acc[0][i][r]))) * rbf(up[r]));
           *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + 8 * my0 + 4 * q) = o;
         }
       }
@@ -166,13 +166,13 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
   for (int i = 0; i < MT; ++i) {
     const int m = 16 * i + c;
     if (m >= a.Bsz) continue;
-    if constexpr (EPI == EPI_SWIGLU) {
+    if constexpr (is_glu<EPI>) {
 #pragma unroll
       for (int j = 0; j + 1 < NTW; j += 2)
         if (j < mine) {
           bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(act_silu(rbf(acc[j][i][r]))) * rbf(acc[j + 1][i][r]));
+          for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(glu_gate<EPI>(rbf(acc[j][i][r]))) * rbf(acc[j + 1][i][r]));
           *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + 8 * (my0 + j) + 4 * q) = o;
         }
     } else {
@@ -218,6 +218,7 @@ int launch_mt(const StreamArgs& a, int epi, dim3 grid, hipStream_t st) {
   switch (epi) {
     case EPI_LINEAR: launch_one<MT, EPI_LINEAR>(a, grid, st); break;
     case EPI_SWIGLU: launch_one<MT, EPI_SWIGLU>(a, grid, st); break;
+    case EPI_GEGLU: launch_one<MT, EPI_GEGLU>(a, grid, st); break;
     case EPI_PARTIAL: launch_one<MT, EPI_PARTIAL>(a, grid, st); break;
     default: return HWOCR_EINVAL;
   }
@@ -232,7 +233,7 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
   const int ktiles = a.K / 64;
   a.ktiles_per_slice = (ktiles + splitk - 1) / splitk;
   if ((splitk - 1) * a.ktiles_per_slice >= ktiles) return HWOCR_EINVAL;  // an empty slice would leave its slab unwritten
-  const int unit = epi == EPI_SWIGLU ? 2 : 1;
+  const int unit = (epi == EPI_SWIGLU || epi == EPI_GEGLU) ? 2 : 1;
   const int units = a.N / 16 / unit, per_wg = WG_TILES / unit;
   // one workgroup per CU: as many tile groups as fill the chip once with this split (more only if a group would exceed
   // 16 tiles; then whole rounds of 256 workgroups)

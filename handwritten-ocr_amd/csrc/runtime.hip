@@ -18,7 +18,6 @@
   } while (0)
 
 namespace {
-constexpr int HD = 128;  // decoder head_dim
 inline bf16* B(void* p) { return (bf16*)p; }
 inline const bf16* B(const void* p) { return (const bf16*)p; }
 inline int pick_splitk(int K, int N, int want_wgs) {
@@ -45,7 +44,7 @@ inline int pick_splitk_stream(int K, int N) {
 }
 }  // namespace
 
-extern "C" int hwocr_abi_version(void) { return 2; }
+extern "C" int hwocr_abi_version(void) { return 3; }
 
 static char g_last_error[256] = "";
 extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text) {
@@ -56,10 +55,12 @@ extern "C" const char* hwocr_last_error(void) { return g_last_error; }
 extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, const void* images, int nimg, int H,
                                  int W, int rows_per_img_ld, const hwocr_vit_layout* lay, void* out, hipStream_t st) {
   if (!m || !ws || !lay || nimg <= 0 || rows_per_img_ld % 64) return HWOCR_EINVAL;
-  const int D = m->dim, hd = D / m->heads, rows = nimg * rows_per_img_ld;
+  const int D = m->dim, rows = nimg * rows_per_img_ld;
+  const int hd = m->head_pad ? m->head_pad : D / m->heads;  // width of a head in Q / K / V^T (zero-padded for SigLIP)
+  const int DH = m->heads * hd;                              // attention width: qkv_w is [3 DH][D], proj_w [D][DH]
   const int P = (H / m->patch) * (W / m->patch);
   const int mm = m->merge * m->merge;
-  const bool v25 = m->kind == HWOCR_VIT_QWEN2_5;
+  const bool v25 = m->kind == HWOCR_VIT_QWEN2_5, sig = m->kind == HWOCR_VIT_SIGLIP;
   // pre-attention / pre-MLP / merger norm of the family
   auto norm = [&](const void* w, const void* b) {
     return v25 ? hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->x, D, w, ws->xn, D, nullptr, rows, D, m->eps, 0, st)
@@ -67,41 +68,54 @@ extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, con
   };
   CHECK(hwocr_patchify(images, m->pixel_lut, ws->patches, nimg, H, W, m->patch, m->merge, m->tps, m->kpad,
                        rows_per_img_ld, lay->row_src, st));
-  CHECK(hwocr_gemm_wide(ws->patches, m->patch_w, nullptr, nullptr, ws->x, rows, D, m->kpad, m->kpad, m->kpad, D, 0,
-                        HWOCR_EPI_LINEAR, st));
-  const float scale = 1.0f / sqrtf((float)hd);
+  if (sig) {
+    // bf16(bf16(conv + bias) + position): the learned positions ride in as the residual operand, page by page
+    if (!m->pos_embed) return HWOCR_EINVAL;
+    for (int i = 0; i < nimg; ++i) {
+      const long r0 = (long)i * rows_per_img_ld;
+      CHECK(hwocr_gemm_wide(B(ws->patches) + r0 * m->kpad, m->patch_w, m->patch_b, m->pos_embed, B(ws->x) + r0 * D, P, D,
+                            m->kpad, m->kpad, m->kpad, D, D, HWOCR_EPI_RESIDUAL, st));
+    }
+  } else {
+    CHECK(hwocr_gemm_wide(ws->patches, m->patch_w, nullptr, nullptr, ws->x, rows, D, m->kpad, m->kpad, m->kpad, D, 0,
+                          HWOCR_EPI_LINEAR, st));
+  }
+  const float scale = 1.0f / sqrtf((float)(D / m->heads));
   for (int l = 0; l < m->depth; ++l) {
     const hwocr_vit_block& b = m->blocks[l];
     CHECK(norm(b.ln1_w, b.ln1_b));
-    CHECK(hwocr_gemm_wide(ws->xn, b.qkv_w, b.qkv_b, nullptr, ws->qkv, rows, 3 * D, D, D, D, 3 * D, 0,
+    CHECK(hwocr_gemm_wide(ws->xn, b.qkv_w, b.qkv_b, nullptr, ws->qkv, rows, 3 * DH, D, D, D, 3 * DH, 0,
                           HWOCR_EPI_LINEAR, st));
     CHECK(hwocr_vit_rope_split(ws->qkv, ws->q, ws->k, ws->vt, lay->pos_h, lay->pos_w, m->rope_cos, m->rope_sin, rows,
                                rows, m->heads, hd, st));
     if (v25 && b.windowed && lay->nwin > 0) {
       CHECK(hwocr_attn_varlen(ws->q, ws->k, ws->vt, ws->attn, lay->win_off, lay->win_lens, lay->nwin, m->heads, hd,
-                              lay->max_win, (long)rows * hd, hd, (long)rows * hd, hd, (long)hd * rows, rows, D, scale,
+                              lay->max_win, (long)rows * hd, hd, (long)rows * hd, hd, (long)hd * rows, rows, DH, scale,
                               st));
     } else {
       CHECK(hwocr_attn_prefill(ws->q, ws->k, ws->vt, ws->attn, lay->seg_lens, nimg, m->heads, 1, hd, P, 0,
                                (long)rows_per_img_ld * hd, (long)rows * hd, hd,   // Q [head][rows][hd]
                                (long)rows_per_img_ld * hd, (long)rows * hd, hd,   // K
                                rows_per_img_ld, (long)hd * rows, rows,            // V^T [head][hd][rows]
-                               (long)rows_per_img_ld * D, D, scale, 0, st));
+                               (long)rows_per_img_ld * DH, DH, scale, 0, st));
     }
-    CHECK(hwocr_gemm_wide(ws->attn, b.proj_w, b.proj_b, ws->x, ws->x, rows, D, D, D, D, D, D, HWOCR_EPI_RESIDUAL, st));
+    CHECK(hwocr_gemm_wide(ws->attn, b.proj_w, b.proj_b, ws->x, ws->x, rows, D, DH, DH, DH, D, D, HWOCR_EPI_RESIDUAL, st));
     CHECK(norm(b.ln2_w, b.ln2_b));
     if (v25) {  // down(silu(gate(x)) * up(x)), all three with bias (HF modeling_qwen2_5_vl.py:84-96)
       CHECK(hwocr_gemm_wide(ws->xn, b.fc1_w, b.fc1_b, nullptr, ws->mlp, rows, 2 * m->mlp_dim, D, D, D, m->mlp_dim, 0,
                             HWOCR_EPI_SWIGLU, st));
     } else {
       CHECK(hwocr_gemm_wide(ws->xn, b.fc1_w, b.fc1_b, nullptr, ws->mlp, rows, m->mlp_dim, D, D, D, m->mlp_dim, 0,
-                            HWOCR_EPI_QUICKGELU, st));
+                            sig ? HWOCR_EPI_GELU_TANH : HWOCR_EPI_QUICKGELU, st));
     }
     CHECK(hwocr_gemm_wide(ws->mlp, b.fc2_w, b.fc2_b, ws->x, ws->x, rows, D, m->mlp_dim, m->mlp_dim, m->mlp_dim, D, D,
                           HWOCR_EPI_RESIDUAL, st));
   }
-  // patch merger: norm -> view(-1, merge^2 * D) -> Linear -> GELU -> Linear
+  // patch merger: norm -> view(-1, merge^2 * D) -> Linear -> GELU -> Linear; SigLIP: post_layernorm -> one projector
   CHECK(norm(m->merger_ln_w, m->merger_ln_b));
+  if (sig)
+    return hwocr_gemm_wide(ws->xn, m->merger_fc2_w, m->merger_fc2_b, nullptr, out, rows, m->out_dim, D, D, D, m->out_dim, 0,
+                           HWOCR_EPI_LINEAR, st);
   const int mrows = rows / mm, MD = mm * D;
   CHECK(hwocr_gemm_wide(ws->xn, m->merger_fc1_w, m->merger_fc1_b, nullptr, ws->merge_mid, mrows, MD, MD, MD, MD, MD, 0,
                         HWOCR_EPI_GELU, st));
@@ -115,38 +129,41 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
                              const int* pos3, const int* seq_lens, const int* last_rows, int nseq, int rows_per_seq,
                              int seq0, int max_len, hipStream_t st) {
   if (!m || !ws || !kv || !gs || nseq <= 0 || rows_per_seq % 64 || rows_per_seq > kv->ctx ||
-      seq0 + nseq > kv->nseq_max || nseq > 128)
+      seq0 + nseq > kv->nseq_max || nseq > 128 || (m->head_dim != 128 && m->head_dim != 256) ||
+      (m->head_dim != 128 && kv->tiled))
     return HWOCR_EINVAL;
+  const int HD = m->head_dim, G = m->gemma;
   const int rows = nseq * rows_per_seq, Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD;
   const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
   const float scale = 1.0f / sqrtf((float)HD);
-  CHECK(hwocr_embed_splice(ids, img_row, m->embed, img_embeds, ws->h, rows, Hd, 1.0f, st));
+  CHECK(hwocr_embed_splice(ids, img_row, m->embed, img_embeds, ws->h, rows, Hd, G ? m->embed_scale : 1.0f, st));
   for (int l = 0; l < m->layers; ++l) {
     const hwocr_dec_layer& L = m->L[l];
     bf16* Kc = B(kv->k) + l * k_layer + seq0 * k_seq;
     bf16* Vc = B(kv->vt) + l * k_layer + seq0 * k_seq;
     CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.in_norm_w, ws->hn, Hd, nullptr, rows, Hd, m->eps,
-                            0, st));
+                            G, st));
     CHECK(hwocr_gemm_wide(ws->hn, L.qkv_w, L.qkv_b, nullptr, ws->qkv, rows, QW, Hd, Hd, Hd, QW, 0, HWOCR_EPI_LINEAR,
                           st));
     CHECK(hwocr_mrope_kv_prefill(ws->qkv, ws->q, Kc, Vc, pos3, m->rope_cos, m->rope_sin, rows, rows_per_seq, m->Hq,
-                                 m->Hkv, m->sec0, m->sec1, k_seq, k_head, k_seq, k_head, kv->ctx, kv->tiled, st));
-    CHECK(hwocr_attn_prefill(ws->q, Kc, Vc, ws->attn, seq_lens, nseq, m->Hq, m->Hq / m->Hkv, HD, max_len, 1,
+                                 m->Hkv, m->sec0, m->sec1, k_seq, k_head, k_seq, k_head, kv->ctx, HD, kv->tiled, st));
+    // Gemma (PaliGemma): the whole prompt is a bidirectional prefix; Qwen: causal
+    CHECK(hwocr_attn_prefill(ws->q, Kc, Vc, ws->attn, seq_lens, nseq, m->Hq, m->Hq / m->Hkv, HD, max_len, G ? 0 : 1,
                              (long)rows_per_seq * m->Hq * HD, HD, (long)m->Hq * HD,  // Q [row][Hq][128]
                              k_seq, k_head, HD, k_seq, k_head, kv->ctx,
                              (long)rows_per_seq * m->Hq * HD, (long)m->Hq * HD, scale, kv->tiled, st));
     CHECK(hwocr_gemm_wide(ws->attn, L.o_w, nullptr, ws->h, ws->h, rows, Hd, m->Hq * HD, m->Hq * HD, m->Hq * HD, Hd, Hd,
                           HWOCR_EPI_RESIDUAL, st));
     CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd, nullptr, rows, Hd,
-                            m->eps, 0, st));
+                            m->eps, G, st));
     CHECK(hwocr_gemm_wide(ws->hn, L.gate_up_w, nullptr, nullptr, ws->act, rows, 2 * m->inter, Hd, Hd, Hd, m->inter, 0,
-                          HWOCR_EPI_SWIGLU, st));
+                          G ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, st));
     CHECK(hwocr_gemm_wide(ws->act, L.down_w, nullptr, ws->h, ws->h, rows, Hd, m->inter, m->inter, m->inter, Hd, Hd,
                           HWOCR_EPI_RESIDUAL, st));
   }
   // final norm on the last prompt token of every read -> LM head -> first generated token
   CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->final_norm_w, ws->hn, Hd, last_rows, nseq, Hd,
-                          m->eps, 0, st));
+                          m->eps, G, st));
   CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head_t ? m->lm_head_t : m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd,
                           Hd, m->vocab, HWOCR_EPI_LINEAR, 1, m->lm_head_t != nullptr, st));
   CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids + seq0, gs->lens + seq0,
@@ -157,8 +174,10 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
 
 extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
                                  const hwocr_gen_state* gs, int nseq, int attn_splits, hipStream_t st) {
-  if (!m || !ws || !kv || !gs || nseq <= 0 || nseq > 256 || nseq > kv->nseq_max || attn_splits < 1)
+  if (!m || !ws || !kv || !gs || nseq <= 0 || nseq > 256 || nseq > kv->nseq_max || attn_splits < 1 ||
+      (m->head_dim != 128 && m->head_dim != 256) || (m->head_dim != 128 && kv->tiled))
     return HWOCR_EINVAL;
+  const int HD = m->head_dim, G = m->gemma;
   const int Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
   const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
   const float scale = 1.0f / sqrtf((float)HD);
@@ -167,9 +186,9 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   const int s_qkv = stream ? pick_splitk_stream(Hd, QW) : pick_splitk(Hd, QW, 400);
   const int s_o = stream ? pick_splitk_stream(OW, Hd) : pick_splitk(OW, Hd, 400);
   const int s_d = stream ? pick_splitk_stream(m->inter, Hd) : pick_splitk(m->inter, Hd, 400);
-  CHECK(hwocr_embed_splice(gs->cur_ids, nullptr, m->embed, nullptr, ws->h, nseq, Hd, 1.0f, st));
+  CHECK(hwocr_embed_splice(gs->cur_ids, nullptr, m->embed, nullptr, ws->h, nseq, Hd, G ? m->embed_scale : 1.0f, st));
   CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->L[0].in_norm_w, ws->hn, Hd, nullptr, nseq, Hd,
-                          m->eps, 0, st));
+                          m->eps, G, st));
   for (int l = 0; l < m->layers; ++l) {
     const hwocr_dec_layer& L = m->L[l];
     bf16* Kc = B(kv->k) + l * k_layer;
@@ -178,20 +197,20 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
                             HWOCR_EPI_PARTIAL, s_qkv, L.qkv_wt != nullptr, st));
     CHECK(hwocr_decode_qkv_finish(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, ws->q, Kc, Vc, gs->lens, gs->rope_delta,
                                   m->rope_cos, m->rope_sin, nseq, m->Hq, m->Hkv, k_seq, k_head, k_seq, k_head,
-                                  kv->ctx, kv->tiled, st));
+                                  kv->ctx, HD, kv->tiled, st));
     CHECK(hwocr_attn_decode(ws->q, Kc, Vc, gs->lens, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv,
-                            attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, kv->tiled, st));
+                            attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, HD, kv->tiled, st));
     CHECK(hwocr_gemm_skinny(ws->attn, L.o_wt ? L.o_wt : L.o_w, nullptr, ws->slabs, nseq, Hd, OW, OW, OW, Hd,
                             HWOCR_EPI_PARTIAL, s_o, L.o_wt != nullptr, st));
     CHECK(hwocr_add_rmsnorm(ws->slabs, s_o, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd,
-                            nullptr, nseq, Hd, m->eps, 0, st));
+                            nullptr, nseq, Hd, m->eps, G, st));
     CHECK(hwocr_gemm_skinny(ws->hn, L.gate_up_wt ? L.gate_up_wt : L.gate_up_w, nullptr, ws->act, nseq, 2 * m->inter, Hd,
-                            Hd, Hd, m->inter, HWOCR_EPI_SWIGLU, 1, L.gate_up_wt != nullptr, st));
+                            Hd, Hd, m->inter, G ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, 1, L.gate_up_wt != nullptr, st));
     CHECK(hwocr_gemm_skinny(ws->act, L.down_wt ? L.down_wt : L.down_w, nullptr, ws->slabs, nseq, Hd, m->inter, m->inter,
                             m->inter, Hd, HWOCR_EPI_PARTIAL, s_d, L.down_wt != nullptr, st));
     const void* next_norm = (l + 1 < m->layers) ? m->L[l + 1].in_norm_w : m->final_norm_w;
     CHECK(hwocr_add_rmsnorm(ws->slabs, s_d, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, next_norm, ws->hn, Hd, nullptr,
-                            nseq, Hd, m->eps, 0, st));
+                            nseq, Hd, m->eps, G, st));
   }
   CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head_t ? m->lm_head_t : m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd,
                           Hd, m->vocab, HWOCR_EPI_LINEAR, 1, m->lm_head_t != nullptr, st));

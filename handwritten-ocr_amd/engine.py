@@ -27,7 +27,6 @@ import torch
 
 from . import _lib, imageproc
 
-HD = 128  # decoder head_dim the kernels are built for
 
 
 @dataclass
@@ -46,7 +45,11 @@ class ModelConfig:
     vit_inter: int = 0
     window_size: int = 112
     fullatt: tuple = (7, 15, 23, 31)
+    # PaliGemma only (family "paligemma"): SigLIP sees a fixed square image; bos token id of the prompt
+    image_size: int = 0
+    bos_id: int = 2
     # decoder
+    head_dim: int = 128   # 128 (Qwen families) or 256 (Gemma)
     hidden: int = 1536
     layers: int = 28
     q_heads: int = 12
@@ -74,9 +77,14 @@ class ModelConfig:
         return self.embed_dim // self.num_heads
 
     @property
+    def vit_hd_pad(self) -> int:
+        """Width of a head inside the attention kernels: SigLIP's 72 is zero-padded to 80 (scores / outputs unchanged)."""
+        return 80 if self.vit_hd == 72 else self.vit_hd
+
+    @property
     def mlp_dim(self) -> int:
         """Width of the tower's MLP activation buffer; the Qwen2.5-VL intermediate size (3420) is zero-padded to x64."""
-        if self.family == "qwen2_5_vl":
+        if self.family in ("qwen2_5_vl", "paligemma"):
             return (self.vit_inter + 63) // 64 * 64
         return int(self.embed_dim * self.mlp_ratio)
 
@@ -89,16 +97,20 @@ class ModelConfig:
         return (self.patch_k + 63) // 64 * 64
 
     def validate(self) -> None:
-        if self.hidden // self.q_heads != HD:
-            raise ValueError(f"decoder head_dim must be {HD}")
-        if self.vit_hd not in (32, 64, 80, 128):
-            raise ValueError("vision head_dim must be one of 32/64/80/128")
+        pg = self.family == "paligemma"
+        if self.head_dim not in (128, 256) or (not pg and self.hidden // self.q_heads != self.head_dim):
+            raise ValueError("decoder head_dim must be 128 (or 256 for Gemma)")
+        if self.vit_hd_pad not in (32, 64, 80, 128):
+            raise ValueError("vision head_dim must be one of 32/64/72/80/128")
         if self.embed_dim % 64 or self.hidden % 64 or self.inter % 64 or self.vocab % 32 or self.mlp_dim % 64:
             raise ValueError("widths must be multiples of 64 (vocab: 32)")
-        if sum(self.mrope_section) * 2 != HD:
+        if not pg and sum(self.mrope_section) * 2 != self.head_dim:
             raise ValueError("mrope_section must sum to head_dim/2")
-        if self.family not in ("qwen2_vl", "qwen2_5_vl"):
+        if self.family not in ("qwen2_vl", "qwen2_5_vl", "paligemma"):
             raise ValueError(f"unknown model family {self.family!r}")
+        if pg and (self.merge != 1 or self.tps != 1 or self.image_size % self.patch_size or self.vit_inter <= 0
+                   or self.q_heads // self.kv_heads > 8):
+            raise ValueError("paligemma needs merge == tps == 1, image_size a multiple of the patch, vit_inter, <= 8 q heads per kv head")
         if self.family == "qwen2_5_vl" and (self.vit_inter <= 0 or self.window_size < self.merge * self.patch_size):
             raise ValueError("qwen2_5_vl needs vit_inter and a window of at least one merged token")
         if self.hidden > 4096 or self.embed_dim > 4096:
@@ -115,6 +127,15 @@ def preset(name: str) -> ModelConfig:
     if name in ("qwen2.5-vl-3b", "Qwen/Qwen2.5-VL-3B-Instruct"):
         return ModelConfig(name="qwen2.5-vl-3b", family="qwen2_5_vl", vit_inter=3420, hidden=2048, layers=36, q_heads=16,
                            kv_heads=2, inter=11008, vocab=151936, tie=True)
+    if name in ("paligemma-3b", "google/paligemma-3b-mix-896"):  # BASELINE config 4 (bf16; fp8 GEMMs are not built)
+        return ModelConfig(name="paligemma-3b", family="paligemma", depth=27, embed_dim=1152, num_heads=16, vit_inter=4304,
+                           merge=1, tps=1, image_size=896, head_dim=256, hidden=2048, layers=18, q_heads=8, kv_heads=1,
+                           inter=16384, vocab=257216, rope_theta=10000.0, tie=True, image_token_id=257152, eos_ids=(1,),
+                           pad_id=0, bos_id=2)
+    if name == "tinypg":  # tests/golden/paligemma_tiny.json
+        return ModelConfig(name="tinypg", family="paligemma", depth=2, embed_dim=576, num_heads=8, vit_inter=600, merge=1,
+                           tps=1, image_size=56, head_dim=256, hidden=256, layers=2, q_heads=2, kv_heads=1, inter=512,
+                           vocab=512, rope_theta=10000.0, tie=True, image_token_id=500, eos_ids=(1,), pad_id=0, bos_id=2)
     if name == "tiny25":  # tests/golden/qwen25vl_tiny.json
         return ModelConfig(name="tiny25", family="qwen2_5_vl", depth=3, embed_dim=64, num_heads=2, vit_inter=88, window_size=56,
                            fullatt=(1,), hidden=256, layers=2, q_heads=2, kv_heads=1, inter=256, vocab=512, image_token_id=500,
@@ -143,6 +164,34 @@ def random_state_dict(cfg: ModelConfig, seed: int = 0, device="cuda", std: float
 
     sd = {}
     D, H = cfg.embed_dim, cfg.hidden
+    HD = cfg.head_dim
+    if cfg.family == "paligemma":
+        v = "model.vision_tower."
+        g = cfg.image_size // cfg.patch_size
+        sd[v + "embeddings.patch_embedding.weight"], sd[v + "embeddings.patch_embedding.bias"] = rn(D, 3, cfg.patch_size, cfg.patch_size), rn(D)
+        sd[v + "embeddings.position_embedding.weight"] = rn(g * g, D)
+        for l in range(cfg.depth):
+            b = f"{v}encoder.layers.{l}."
+            for n in ("layer_norm1", "layer_norm2"):
+                sd[b + n + ".weight"], sd[b + n + ".bias"] = ones_ish(D), rn(D)
+            for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                sd[b + f"self_attn.{n}.weight"], sd[b + f"self_attn.{n}.bias"] = rn(D, D), rn(D)
+            sd[b + "mlp.fc1.weight"], sd[b + "mlp.fc1.bias"] = rn(cfg.vit_inter, D), rn(cfg.vit_inter)
+            sd[b + "mlp.fc2.weight"], sd[b + "mlp.fc2.bias"] = rn(D, cfg.vit_inter), rn(D)
+        sd[v + "post_layernorm.weight"], sd[v + "post_layernorm.bias"] = ones_ish(D), rn(D)
+        sd["model.multi_modal_projector.linear.weight"], sd["model.multi_modal_projector.linear.bias"] = rn(H, D), rn(H)
+        t = "model.language_model."
+        sd[t + "embed_tokens.weight"] = rn(cfg.vocab, H)
+        for l in range(cfg.layers):
+            p = f"{t}layers.{l}."
+            sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = rn(H), rn(H)  # (1 + w) norms
+            sd[p + "self_attn.q_proj.weight"] = rn(cfg.q_heads * HD, H)
+            sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = rn(cfg.kv_heads * HD, H), rn(cfg.kv_heads * HD, H)
+            sd[p + "self_attn.o_proj.weight"] = rn(H, cfg.q_heads * HD)
+            sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = rn(cfg.inter, H), rn(cfg.inter, H)
+            sd[p + "mlp.down_proj.weight"] = rn(H, cfg.inter)
+        sd[t + "norm.weight"] = rn(H)
+        return sd
     v = "model.visual."
     sd[v + "patch_embed.proj.weight"] = rn(D, 3, cfg.tps, cfg.patch_size, cfg.patch_size)
     v25 = cfg.family == "qwen2_5_vl"
@@ -190,9 +239,14 @@ def normalize_keys(sd: dict) -> dict:
     model.language_model.*` (transformers >= 4.52)."""
     out = {}
     for k, v in sd.items():
-        if k.startswith("visual."):
+        if k.startswith(("vision_tower.", "multi_modal_projector.", "language_model.model.")):  # PaliGemma, transformers < 4.52
+            k = "model." + k.replace("vision_tower.vision_model.", "vision_tower.").replace("language_model.model.", "language_model.")
+        elif k.startswith("model.vision_tower.vision_model."):
+            k = k.replace("vision_tower.vision_model.", "vision_tower.")
+        elif k.startswith("visual."):
             k = "model." + k
-        elif k.startswith("model.") and not k.startswith(("model.visual.", "model.language_model.")):
+        elif k.startswith("model.") and not k.startswith(("model.visual.", "model.language_model.", "model.vision_tower.",
+                                                          "model.multi_modal_projector.")):
             k = "model.language_model." + k[len("model."):]
         out[k] = v
     return out
@@ -274,6 +328,68 @@ class ReadEngine:
         return out
 
     def _bind_weights(self, sd: dict) -> None:
+        if self.cfg.family == "paligemma":
+            self._bind_vision_siglip(sd)
+        else:
+            self._bind_vision_qwen(sd)
+        self._bind_decoder(sd)
+
+    def _bind_vision_siglip(self, sd: dict) -> None:
+        """SigLIP tower + projector (HF siglip/modeling_siglip.py:116-356, paligemma/modeling_paligemma.py:90-98) on the
+        kernels of the Qwen towers: q/k/v fused into one GEMM whose head rows are zero-padded 72 -> 80 (out_proj gets
+        zero columns), so the head-dim-80 attention kernel runs unchanged with scale 72^-1/2; no rotary (the rope kernel
+        sees position 0 = identity); learned positions are the residual operand of the patch GEMM."""
+        c, P, dev, bf = self.cfg, _lib.ptr, self.dev, torch.bfloat16
+        v = "model.vision_tower."
+        D, Hn, hd, hp = c.embed_dim, c.num_heads, c.vit_hd, c.vit_hd_pad
+        pw = torch.zeros(D, c.kpad, dtype=bf, device=dev)
+        pw[:, : c.patch_k] = sd[v + "embeddings.patch_embedding.weight"].reshape(D, -1).to(dev, bf)
+        self._keep.append(pw)
+
+        def pad_heads_rows(w):   # [Hn*hd, ...] -> [Hn*hp, ...]
+            w = w.to(dev, bf)
+            out = torch.zeros((Hn, hp) + tuple(w.shape[1:]), dtype=bf, device=dev)
+            out[:, :hd] = w.reshape((Hn, hd) + tuple(w.shape[1:]))
+            return out.reshape((Hn * hp,) + tuple(w.shape[1:]))
+
+        def pad_rows(w, n):
+            w = w.to(dev, bf)
+            out = torch.zeros((n,) + tuple(w.shape[1:]), dtype=bf, device=dev)
+            out[: w.shape[0]] = w
+            return out
+
+        blocks = (_lib.VitBlock * c.depth)()
+        for l in range(c.depth):
+            b = f"{v}encoder.layers.{l}."
+            qkv_w = torch.cat([pad_heads_rows(sd[b + f"self_attn.{n}_proj.weight"]) for n in "qkv"], dim=0)
+            qkv_b = torch.cat([pad_heads_rows(sd[b + f"self_attn.{n}_proj.bias"]) for n in "qkv"], dim=0)
+            ow = sd[b + "self_attn.out_proj.weight"].to(dev, bf)                        # [D][Hn*hd]
+            proj_w = torch.zeros(D, Hn, hp, dtype=bf, device=dev)
+            proj_w[:, :, :hd] = ow.reshape(D, Hn, hd)
+            fc2 = torch.zeros(D, c.mlp_dim, dtype=bf, device=dev)
+            fc2[:, : c.vit_inter] = sd[b + "mlp.fc2.weight"].to(dev, bf)
+            B = blocks[l]
+            B.ln1_w, B.ln1_b = P(self._t(sd[b + "layer_norm1.weight"])), P(self._t(sd[b + "layer_norm1.bias"]))
+            B.ln2_w, B.ln2_b = P(self._t(sd[b + "layer_norm2.weight"])), P(self._t(sd[b + "layer_norm2.bias"]))
+            B.qkv_w, B.qkv_b = P(self._t(qkv_w)), P(self._t(qkv_b))
+            B.proj_w, B.proj_b = P(self._t(proj_w.reshape(D, Hn * hp))), P(self._t(sd[b + "self_attn.out_proj.bias"]))
+            B.fc1_w, B.fc1_b = P(self._t(pad_rows(sd[b + "mlp.fc1.weight"], c.mlp_dim))), P(self._t(pad_rows(sd[b + "mlp.fc1.bias"], c.mlp_dim)))
+            B.fc2_w, B.fc2_b = P(self._t(fc2)), P(self._t(sd[b + "mlp.fc2.bias"]))
+        # identity rotation table for the (unused) rotary of the shared rope/split kernel: row 0 = (cos 1, sin 0)
+        self.vit_cos = torch.ones(8, hp // 4, dtype=torch.float32, device=dev)
+        self.vit_sin = torch.zeros(8, hp // 4, dtype=torch.float32, device=dev)
+        self.lut = torch.from_numpy(imageproc.pixel_lut((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))).to(bf).to(dev)
+        self.vit = _lib.Vit(depth=c.depth, dim=D, heads=Hn, mlp_dim=c.mlp_dim, patch=c.patch_size, merge=1, tps=1, kpad=c.kpad,
+                            out_dim=c.hidden, kind=2, head_pad=hp if hp != hd else 0, eps=1e-6, patch_w=P(pw), blocks=blocks,
+                            merger_ln_w=P(self._t(sd[v + "post_layernorm.weight"])), merger_ln_b=P(self._t(sd[v + "post_layernorm.bias"])),
+                            merger_fc2_w=P(self._t(sd["model.multi_modal_projector.linear.weight"])),
+                            merger_fc2_b=P(self._t(sd["model.multi_modal_projector.linear.bias"])),
+                            rope_cos=P(self.vit_cos), rope_sin=P(self.vit_sin), pixel_lut=P(self.lut),
+                            patch_b=P(self._t(sd[v + "embeddings.patch_embedding.bias"])),
+                            pos_embed=P(self._t(sd[v + "embeddings.position_embedding.weight"])))
+        self._keep.append(blocks)
+
+    def _bind_vision_qwen(self, sd: dict) -> None:
         c = self.cfg
         P = _lib.ptr
         v = "model.visual."
@@ -330,14 +446,17 @@ class ReadEngine:
                             rope_cos=P(self.vit_cos), rope_sin=P(self.vit_sin), pixel_lut=P(self.lut))
         self._keep.append(blocks)
 
+    def _bind_decoder(self, sd: dict) -> None:
+        c, P, HD = self.cfg, _lib.ptr, self.cfg.head_dim
+        gemma = c.family == "paligemma"
         t = "model.language_model."
         layers = (_lib.DecLayer * c.layers)()
         for l in range(c.layers):
             p = f"{t}layers.{l}."
             qkv_w = torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"],
                                sd[p + "self_attn.v_proj.weight"]], dim=0)
-            qkv_b = torch.cat([sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"],
-                               sd[p + "self_attn.v_proj.bias"]], dim=0)
+            qkv_b = None if gemma else torch.cat([sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"],
+                                                  sd[p + "self_attn.v_proj.bias"]], dim=0)
             # gate/up rows interleaved in 16-row tiles so one MFMA tile pair yields silu(gate)*up (csrc/gemm.hip)
             g = sd[p + "mlp.gate_proj.weight"].reshape(c.inter // 16, 16, c.hidden)
             u = sd[p + "mlp.up_proj.weight"].reshape(c.inter // 16, 16, c.hidden)
@@ -346,7 +465,7 @@ class ReadEngine:
             w_qkv, w_o = self._t(qkv_w), self._t(sd[p + "self_attn.o_proj.weight"])
             w_gu, w_down = self._t(gu), self._t(sd[p + "mlp.down_proj.weight"])
             L.in_norm_w = P(self._t(sd[p + "input_layernorm.weight"]))
-            L.qkv_w, L.qkv_b = P(w_qkv), P(self._t(qkv_b))
+            L.qkv_w, L.qkv_b = P(w_qkv), (None if qkv_b is None else P(self._t(qkv_b)))
             L.o_w = P(w_o)
             L.post_norm_w = P(self._t(sd[p + "post_attention_layernorm.weight"]))
             L.gate_up_w, L.down_w = P(w_gu), P(w_down)
@@ -360,8 +479,11 @@ class ReadEngine:
         self.dec_cos = ang.cos().to(torch.bfloat16).contiguous().to(self.dev)
         self.dec_sin = ang.sin().to(torch.bfloat16).contiguous().to(self.dev)
         self.max_pos = ang.shape[0]
+        # Gemma: plain RoPE = every frequency on the first position axis (sec0 past the last frequency)
+        sec0, sec1 = (HD, HD) if gemma else (c.mrope_section[0], c.mrope_section[0] + c.mrope_section[1])
         self.dec = _lib.Decoder(layers=c.layers, hidden=c.hidden, Hq=c.q_heads, Hkv=c.kv_heads, inter=c.inter, vocab=c.vocab,
-                                sec0=c.mrope_section[0], sec1=c.mrope_section[0] + c.mrope_section[1], eps=c.eps,
+                                sec0=sec0, sec1=sec1, head_dim=HD, gemma=1 if gemma else 0, eps=c.eps,
+                                embed_scale=float(c.hidden) ** 0.5,
                                 embed=P(embed), lm_head=P(head), lm_head_t=P(self._tiled(head)), final_norm_w=P(self._t(sd[t + "norm.weight"])), L=layers,
                                 rope_cos=P(self.dec_cos), rope_sin=P(self.dec_sin))
         self._keep.append(layers)
@@ -371,10 +493,13 @@ class ReadEngine:
     def _alloc_state(self) -> None:
         c, R, dev = self.cfg, self.max_reads, self.dev
         bf = torch.bfloat16
+        HD = c.head_dim
         kv_elems = c.layers * R * c.kv_heads * self.ctx * HD
         self.k_cache = torch.zeros(kv_elems, dtype=bf, device=dev)
         self.vt_cache = torch.zeros(kv_elems, dtype=bf, device=dev)
-        self.kv = _lib.Kv(k=_lib.ptr(self.k_cache), vt=_lib.ptr(self.vt_cache), nseq_max=R, ctx=self.ctx, tiled=1)
+        # fragment-tiled cache for head_dim 128; Gemma's 256-wide heads use the row layout
+        self.kv = _lib.Kv(k=_lib.ptr(self.k_cache), vt=_lib.ptr(self.vt_cache), nseq_max=R, ctx=self.ctx,
+                          tiled=1 if HD == 128 else 0)
         i32 = dict(dtype=torch.int32, device=dev)
         self.cur_ids = torch.zeros(R, **i32)
         self.lens = torch.zeros(R, **i32)
@@ -392,6 +517,7 @@ class ReadEngine:
         c, dev, bf = self.cfg, self.dev, torch.bfloat16
         if self._ws_dec is None or rows > self._ws_rows:
             R = self.max_reads
+            HD = c.head_dim
             QW = (c.q_heads + 2 * c.kv_heads) * HD
             slab_elems = 40 * R * max(QW, c.hidden)  # split-K never exceeds ceil(K/256) <= 35 slices here
             splits = 16
@@ -411,13 +537,13 @@ class ReadEngine:
     def _vit_ws(self, rows: int) -> _lib.VitWs:
         c, dev, bf = self.cfg, self.dev, torch.bfloat16
         if rows > self._vit_rows:
-            D, hd = c.embed_dim, c.vit_hd
+            D, DH = c.embed_dim, c.num_heads * c.vit_hd_pad
             mm = c.merge ** 2
             self._vbufs = dict(
-                patches=torch.zeros(rows, c.kpad, dtype=bf, device=dev), x=torch.empty(rows, D, dtype=bf, device=dev),
-                xn=torch.empty(rows, D, dtype=bf, device=dev), qkv=torch.empty(rows, 3 * D, dtype=bf, device=dev),
-                q=torch.empty(rows * D, dtype=bf, device=dev), k=torch.empty(rows * D, dtype=bf, device=dev),
-                vt=torch.zeros(rows * D + 64, dtype=bf, device=dev), attn=torch.empty(rows, D, dtype=bf, device=dev),
+                patches=torch.zeros(rows, c.kpad, dtype=bf, device=dev), x=torch.zeros(rows, D, dtype=bf, device=dev),
+                xn=torch.empty(rows, D, dtype=bf, device=dev), qkv=torch.empty(rows, 3 * DH, dtype=bf, device=dev),
+                q=torch.empty(rows * DH, dtype=bf, device=dev), k=torch.empty(rows * DH, dtype=bf, device=dev),
+                vt=torch.zeros(rows * DH + 64, dtype=bf, device=dev), attn=torch.empty(rows, DH, dtype=bf, device=dev),
                 mlp=torch.empty(rows, c.mlp_dim, dtype=bf, device=dev),
                 merge_mid=torch.empty(rows // mm, D * mm, dtype=bf, device=dev))
             self._vit_rows = rows
@@ -455,6 +581,8 @@ class ReadEngine:
             P = gh * gw
             Pp = _ceil(P, 64)
             ph, pw = imageproc.vision_positions(gh, gw, c.merge)
+            if c.family == "paligemma":  # no rotary in SigLIP: position 0 is the identity row of the table
+                ph, pw = np.zeros_like(ph), np.zeros_like(pw)
             slot = np.arange(P // mm, dtype=np.int32)  # buffer slot (within the page) of merged token i
             if v25:
                 order, win_lens = imageproc.window_order(gh, gw, c.merge, c.window_size, c.patch_size)
@@ -542,7 +670,10 @@ class ReadEngine:
             if len(m) != n_img:
                 raise ValueError(f"read {r}: {len(m)} image placeholders but the page yields {n_img} image tokens")
             img_row[r, m] = tok_rows[r]
-            pos3[:, r, : T[r]], delta[r] = imageproc.mrope_positions(p, c.image_token_id, [grids[r]], c.merge)
+            if c.family == "paligemma":  # 1-indexed plain positions (HF paligemma/modeling_paligemma.py:237)
+                pos3[:, r, : T[r]], delta[r] = np.arange(1, T[r] + 1, dtype=np.int32), 1
+            else:
+                pos3[:, r, : T[r]], delta[r] = imageproc.mrope_positions(p, c.image_token_id, [grids[r]], c.merge)
         if int(pos3.max()) + max_new + 2 > self.max_pos:
             raise ValueError("rope table too short for this prompt")
         d_ids = torch.from_numpy(ids).to(dev)

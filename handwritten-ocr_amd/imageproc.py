@@ -45,11 +45,21 @@ def prepare_page(img: Image.Image, patch: int, merge: int, min_pixels: int, max_
     return np.asarray(img, dtype=np.uint8)
 
 
-def pixel_lut() -> np.ndarray:
-    """float32 [3][256]: the normalised value of every (channel, byte)."""
+def prepare_square(img: Image.Image, size: int) -> np.ndarray:
+    """PIL page -> uint8 [size, size, 3]: the SigLIP processor's plain bicubic resize, aspect not kept
+    (HF siglip/image_processing_pil_siglip.py: size {height, width}, resample BICUBIC)."""
+    if img.mode != "RGB":
+        img = img.convert("RGB")
+    if (img.height, img.width) != (size, size):
+        img = img.resize((size, size), resample=Image.BICUBIC, reducing_gap=None)
+    return np.asarray(img, dtype=np.uint8)
+
+
+def pixel_lut(image_mean=IMAGE_MEAN, image_std=IMAGE_STD) -> np.ndarray:
+    """float32 [3][256]: the normalised value of every (channel, byte).  SigLIP / PaliGemma: mean = std = 0.5."""
     v = (np.arange(256, dtype=np.uint8).astype(np.float64) * (1 / 255)).astype(np.float32)
-    mean = np.array(IMAGE_MEAN, dtype=np.float32)
-    std = np.array(IMAGE_STD, dtype=np.float32)
+    mean = np.array(image_mean, dtype=np.float32)
+    std = np.array(image_std, dtype=np.float32)
     return ((v[None, :] - mean[:, None]) / std[:, None]).astype(np.float32)
 
 

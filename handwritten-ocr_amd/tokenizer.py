@@ -67,6 +67,8 @@ class Processor:
 
     def chat_ids(self, prompt: str, n_image_tokens: int) -> np.ndarray:
         c, enc = self.cfg, self.tokenizer.encode
+        if c.family == "paligemma":  # <image> x n, <bos>, prompt, newline (HF paligemma/processing_paligemma.py build_string_from_input)
+            return np.asarray([c.image_token_id] * n_image_tokens + [c.bos_id] + enc(prompt) + enc("\n"), dtype=np.int32)
         ids = ([c.im_start_id] + enc("system\n" + SYSTEM_TEXT) + [c.im_end_id] + enc("\n")
                + [c.im_start_id] + enc("user\n") + [c.vision_start_id] + [c.image_token_id] * n_image_tokens
                + [c.vision_end_id] + enc(prompt) + [c.im_end_id] + enc("\n") + [c.im_start_id] + enc("assistant\n"))
@@ -76,6 +78,9 @@ class Processor:
         from . import imageproc
 
         c = self.cfg
+        if c.family == "paligemma":
+            page = imageproc.prepare_square(img, c.image_size)
+            return page, self.chat_ids(prompt, self.image_tokens(page))
         page = imageproc.prepare_page(img, c.patch_size, c.merge, c.min_pixels, c.max_pixels)
         return page, self.chat_ids(prompt, self.image_tokens(page))
 

@@ -35,6 +35,8 @@ typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
 #define HWOCR_EPI_GELU 3
 #define HWOCR_EPI_SWIGLU 4
 #define HWOCR_EPI_PARTIAL 5
+#define HWOCR_EPI_GELU_TANH 6 /* nn.GELU(approximate="tanh"): SigLIP MLP (HF siglip/modeling_siglip.py:310-322) */
+#define HWOCR_EPI_GEGLU 7     /* SWIGLU's interleaved tile pairs with the tanh GELU as gate: Gemma MLP (HF gemma/modeling_gemma.py:84-97) */
 
 int hwocr_abi_version(void);
 /* text of the most recent launch failure in this process ("" if none): launcher name + HIP error */
@@ -71,11 +73,12 @@ int hwocr_attn_varlen(const void* Q, const void* K, const void* VT, void* O, con
                       int nseg, int heads, int head_dim, int max_len, long q_head, long q_row, long k_head,
                       long k_row, long v_head, long v_row, long o_row, float scale, hwocr_stream_t stream);
 
-/* One query token per read against its KV cache (HF modeling_qwen2_vl.py:553-569 with q_len == 1). head_dim 128.
- * kv_tiled (here and in the cache writers below): the cache is in the fragment-tiled layout, strides k_row/v_row unused. */
+/* One query token per read against its KV cache (HF modeling_qwen2_vl.py:553-569 with q_len == 1).  head_dim 128, or 256
+ * (Gemma) with the row layout only.  kv_tiled (here and in the cache writers below): the cache is in the fragment-tiled
+ * layout, strides k_row/v_row unused. */
 int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out, float* part_o,
                       float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head, long v_seq,
-                      long v_head, long v_row, float scale, int kv_tiled, hwocr_stream_t stream);
+                      long v_head, long v_row, float scale, int head_dim, int kv_tiled, hwocr_stream_t stream);
 
 /* uint8 HWC resized pages -> bf16 patch rows (HF image_processing_pil_qwen2_vl.py:152-187, :226-229).
  * row_src (optional, device int32 [gh*gw]): output row r of every image shows patch row_src[r] of the processor's
@@ -96,16 +99,17 @@ int hwocr_vit_rope_split(const void* qkv, void* Q, void* K, void* VT, const int*
                          hwocr_stream_t stream);
 
 /* rows are laid out [nseq][rows_per_seq]; row r belongs to read r / rows_per_seq (K, VT point at the first read's
- * cache), cache slot r % rows_per_seq */
+ * cache), cache slot r % rows_per_seq.  head_dim 128 or 256; rope tables [maxpos][head_dim/2]; sec0 >= head_dim/2 turns
+ * the three-axis M-RoPE into plain RoPE on pos[0] (Gemma) */
 int hwocr_mrope_kv_prefill(const void* qkv, void* Q, void* K, void* VT, const int* pos, const void* cos_tab,
                            const void* sin_tab, int rows, int rows_per_seq, int Hq, int Hkv, int sec0, int sec1,
-                           long k_seq, long k_head, long v_seq, long v_head, long v_row, int kv_tiled,
+                           long k_seq, long k_head, long v_seq, long v_head, long v_row, int head_dim, int kv_tiled,
                            hwocr_stream_t stream);
 
 int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_stride, const void* bias, void* Q, void* K,
                             void* VT, const int* lens, const int* rope_delta, const void* cos_tab,
                             const void* sin_tab, int nseq, int Hq, int Hkv, long k_seq, long k_head, long v_seq,
-                            long v_head, long v_row, int kv_tiled, hwocr_stream_t stream);
+                            long v_head, long v_row, int head_dim, int kv_tiled, hwocr_stream_t stream);
 
 int hwocr_embed_splice(const int* ids, const int* img_row, const void* table, const void* img, void* out, int rows,
                        int D, float scale, hwocr_stream_t stream);
@@ -118,6 +122,8 @@ int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_
 
 #define HWOCR_VIT_QWEN2 0   /* LayerNorm, fc1 -> QuickGELU -> fc2 (HF modeling_qwen2_vl.py:421-437) */
 #define HWOCR_VIT_QWEN2_5 1 /* RMSNorm, biased gate/up/down SiLU MLP, windowed attention (HF modeling_qwen2_5_vl.py:293-322) */
+#define HWOCR_VIT_SIGLIP 2  /* PaliGemma tower: biased patch conv + learned positions, LayerNorm, fc1 -> tanh GELU -> fc2, no rotary,
+                             * post-LayerNorm, one linear projector (HF siglip/modeling_siglip.py:116-356, paligemma/modeling_paligemma.py:90-98) */
 
 typedef struct {
   /* QWEN2_5: ln*_b unused; fc1_w/fc1_b = gate_proj/up_proj rows interleaved in 16-row tiles [2*mlp_dim][dim] (+ bias
@@ -128,12 +134,15 @@ typedef struct {
 
 typedef struct {
   int depth, dim, heads, mlp_dim, patch, merge, tps, kpad, out_dim, kind;
+  int head_pad; /* 0, or the width heads are zero-padded to in Q/K/V^T and in the rows of qkv_w / columns of proj_w (SigLIP:
+                 * head_dim 72 -> 80, scores and outputs unchanged; softmax scale stays (dim/heads)^-1/2) */
   float eps;
   const void* patch_w;            /* [dim][kpad], zero beyond 3*tps*patch^2 */
   const hwocr_vit_block* blocks;  /* host array[depth] of device pointers */
   const void *merger_ln_w, *merger_ln_b, *merger_fc1_w, *merger_fc1_b, *merger_fc2_w, *merger_fc2_b;
   const float *rope_cos, *rope_sin; /* fp32 [maxpos][head_dim/4] */
   const void* pixel_lut;            /* bf16 [3][256] */
+  const void *patch_b, *pos_embed;  /* SIGLIP: conv bias [dim], learned positions [patches][dim]; else NULL */
 } hwocr_vit;
 
 typedef struct { /* all device buffers, rows = nimg * rows_per_img_ld; vt holds 64 elements of slack past rows*dim */
@@ -160,7 +169,10 @@ typedef struct {
 
 typedef struct {
   int layers, hidden, Hq, Hkv, inter, vocab, sec0, sec1;
-  float eps;
+  int head_dim; /* 128, or 256 (Gemma: KV cache in the row layout) */
+  int gemma;    /* Gemma conventions (HF gemma/modeling_gemma.py): norms scale by (1 + w) in fp32, tanh-GELU gate, token
+                 * embeddings times bf16(embed_scale), the prompt is a bidirectional prefix (paligemma/modeling_paligemma.py:256-262) */
+  float eps, embed_scale;
   const void* embed;        /* [vocab][hidden] */
   const void* lm_head;      /* [vocab][hidden] (may alias embed) */
   const void* lm_head_t;    /* fragment-tiled copy of lm_head for decode (may be NULL) */

@@ -54,3 +54,23 @@ def test_positions_match_oracle():
     assert np.array_equal(pos, wpos.numpy()) and delta == wdelta
     with pytest.raises(ValueError):
         imageproc.mrope_positions(ids, 9, [(1, 4, 4), (1, 2, 4)], 2)
+
+
+def test_siglip_square_resize_and_lut_match_hf():
+    """PaliGemma / SigLIP preprocessing: plain bicubic resize to the tower size, (x/255 - 0.5)/0.5 — against the HF
+    SiglipImageProcessorPil output stored with the PaliGemma goldens."""
+    import os
+
+    import torch
+    from safetensors.torch import load_file
+
+    from handwritten_ocr_amd import imageproc
+    from tests._golden import GOLD
+    from PIL import Image
+
+    g = load_file(os.path.join(GOLD, "paligemma_tiny_fp32.safetensors"))
+    lut = imageproc.pixel_lut((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+    for case in ("a", "b"):
+        page = imageproc.prepare_square(Image.fromarray(g[f"{case}.page"].numpy(), "RGB"), 56)
+        got = np.stack([lut[c][page[:, :, c]] for c in range(3)])
+        assert np.array_equal(got, g[f"{case}.pixel_values"].numpy())

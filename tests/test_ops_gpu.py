@@ -30,24 +30,27 @@ def _epilogue_ref(acc, bias, res, epi):
     if epi == 3:
         x = rbf(v)
         return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    if epi == 6:
+        return torch.nn.functional.gelu(rbf(v), approximate="tanh")
     raise AssertionError
 
 
-def _swiglu_ref(acc, bias=None):
-    # weight (and bias) rows interleaved [16 gate][16 up]
+def _swiglu_ref(acc, bias=None, geglu=False):
+    # weight (and bias) rows interleaved [16 gate][16 up]; geglu: tanh GELU instead of SiLU on the gate (Gemma)
     M, N = acc.shape
     if bias is not None:
         acc = acc + bias.float()
     a = acc.view(M, N // 32, 2, 16)
     g, u = rbf(a[:, :, 0, :]), rbf(a[:, :, 1, :])
-    return (rbf(torch.nn.functional.silu(g)) * u).reshape(M, N // 2)
+    act = torch.nn.functional.gelu(g, approximate="tanh") if geglu else torch.nn.functional.silu(g)
+    return (rbf(act) * u).reshape(M, N // 2)
 
 
 # shapes with M >= 1024 and N >= 256 run the 256x256 8-wave kernel (gemm256.hip), the others the 128x128 one
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1000, 384, 1216), (257, 1536, 1536),
                                    (1024, 256, 64), (1300, 512, 128), (2048, 768, 1216), (1111, 1000, 192),
                                    (5184, 1280, 320)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 6])
 def test_gemm_wide(M, N, K, epi):
     x = randbf(M, K, scale=1.0, seed=1)
     w = randbf(N, K, scale=K ** -0.5, seed=2)
@@ -83,6 +86,16 @@ def test_gemm_wide_swiglu(M, N, K, with_bias):
     # the ulp budget is taken at |out| * (1 + |g|)
     gate = rbf((acc + (bias.float() if with_bias else 0.0)).view(M, N // 32, 2, 16)[:, :, 0, :]).reshape(M, N // 2)
     assert_close_bf16(out, want, ulps=3.0, atol=2e-3, what="gemm_wide swiglu", mag=want.abs() * (1.0 + gate.abs()))
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (1328, 1792, 1536)])
+def test_gemm_wide_geglu(M, N, K):
+    x = randbf(M, K, seed=5)
+    w = randbf(N, K, scale=K ** -0.5, seed=6)
+    out = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert lib().hwocr_gemm_wide(p(x), p(w), None, None, p(out), M, N, K, K, K, N // 2, 0, 7, st()) == 0
+    sync()
+    assert_close_bf16(out, _swiglu_ref(x.float() @ w.float().t(), geglu=True), ulps=3.0, atol=2e-3, what="gemm_wide geglu")
 
 
 def test_gemm_wide_rejects_bad_shapes():
@@ -137,10 +150,12 @@ def test_gemm_skinny_swiglu(B, tiled):
     x = randbf(B, K, seed=10)
     w = randbf(N, K, scale=K ** -0.5, seed=11)
     wk = _tiled(w) if tiled else w
-    out = torch.full((B, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
-    assert lib().hwocr_gemm_skinny(p(x), p(wk), None, p(out), B, N, K, K, K, N // 2, 4, 1, tiled, st()) == 0
-    sync()
-    assert_close_bf16(out, _swiglu_ref(x.float() @ w.float().t()), ulps=3.0, atol=2e-3, what="skinny swiglu")
+    for epi, geglu in ((4, False), (7, True)):  # SwiGLU (Qwen), GeGLU (Gemma)
+        out = torch.full((B, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+        assert lib().hwocr_gemm_skinny(p(x), p(wk), None, p(out), B, N, K, K, K, N // 2, epi, 1, tiled, st()) == 0
+        sync()
+        assert_close_bf16(out, _swiglu_ref(x.float() @ w.float().t(), geglu=geglu), ulps=3.0, atol=2e-3,
+                          what=f"skinny glu epi={epi}")
 
 
 # ------------------------------------------------------------------------------------------------ attention
@@ -157,7 +172,8 @@ def _sdpa_ref(q, k, v, causal, scale):
 
 
 @pytest.mark.parametrize("hd,Hq,Hkv,causal,tiled", [(80, 4, 4, False, 0), (128, 6, 2, True, 0), (32, 2, 2, False, 0),
-                                                     (64, 2, 1, True, 0), (128, 2, 2, False, 0), (128, 6, 2, True, 1)])
+                                                     (64, 2, 1, True, 0), (128, 2, 2, False, 0), (128, 6, 2, True, 1),
+                                                     (256, 4, 1, False, 0), (256, 2, 1, True, 0)])
 def test_attn_prefill(hd, Hq, Hkv, causal, tiled):
     lens = [300, 64, 37, 129]
     nseg, Lp = len(lens), 320  # per-segment stride, multiple of 64
@@ -216,10 +232,11 @@ def test_attn_varlen_windows(hd, heads):
     assert (out[offs[-1] + lens[-1]:] == 0).all(), "rows outside every window must stay untouched"
 
 
-@pytest.mark.parametrize("tiled", [0, 1])
+# hd 256: Gemma (MQA: 8 query heads on one kv head), row layout only
+@pytest.mark.parametrize("hd,Hq,Hkv,tiled", [(128, 12, 2, 0), (128, 12, 2, 1), (256, 8, 1, 0)])
 @pytest.mark.parametrize("nsplit", [1, 4])
-def test_attn_decode(nsplit, tiled):
-    Hq, Hkv, hd, ctx = 12, 2, 128, 640
+def test_attn_decode(nsplit, hd, Hq, Hkv, tiled):
+    ctx = 640
     lens = [1, 63, 64, 65, 500, 640]
     B = len(lens)
     q = randbf(B, Hq, hd, seed=15)
@@ -236,7 +253,7 @@ def test_attn_decode(nsplit, tiled):
     lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
     kk, vv = (tile_k(k), tile_v(vt)) if tiled else (k, vt)
     rc = lib().hwocr_attn_decode(p(q), p(kk), p(vv), p(lens_d), p(out), p(part_o), p(part_ml), B, Hq, Hkv, nsplit,
-                                 Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, tiled, st())
+                                 Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, hd, tiled, st())
     assert rc == 0
     sync()
     for b, n in enumerate(lens):
@@ -370,69 +387,71 @@ def test_vit_rope_split(hd, heads):
 
 
 def _mrope_ref(x, pos3, cos_tab, sin_tab, sec0, sec1):
-    # x [rows, heads, 128] fp32 (bf16 values); tables bf16 [maxpos][64]; returns fp32 of the bf16 result
-    i = torch.arange(64)
+    # x [rows, heads, hd] fp32 (bf16 values); tables bf16 [maxpos][hd/2]; returns fp32 of the bf16 result
+    half = x.shape[-1] // 2
+    i = torch.arange(half)
     axis = torch.where(i < sec0, 0, torch.where(i < sec1, 1, 2))
-    pidx = pos3[axis, :].t().long()  # [rows, 64]
-    cs = cos_tab.float()[pidx, i].unsqueeze(1)  # [rows,1,64]
+    pidx = pos3[axis, :].t().long()  # [rows, half]
+    cs = cos_tab.float()[pidx, i].unsqueeze(1)  # [rows,1,half]
     sn = sin_tab.float()[pidx, i].unsqueeze(1)
-    x1, x2 = x[..., :64], x[..., 64:]
+    x1, x2 = x[..., :half], x[..., half:]
     oa = rbf(rbf(x1 * cs) + rbf(-x2 * sn))
     ob = rbf(rbf(x2 * cs) + rbf(x1 * sn))
     return torch.cat([oa, ob], -1)
 
 
-def _rope_tables(maxpos, theta=1e6):
-    inv = 1.0 / (theta ** (torch.arange(0, 128, 2, dtype=torch.float) / 128))
+def _rope_tables(maxpos, theta=1e6, hd=128):
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
     fr = torch.arange(maxpos, dtype=torch.float).unsqueeze(-1) * inv
     return fr.cos().to(torch.bfloat16), fr.sin().to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("tiled", [0, 1])
-def test_mrope_kv_prefill(tiled):
+# hd 256 with sec0 = 128: plain RoPE on the first position axis (Gemma)
+@pytest.mark.parametrize("hd,sec0,sec1,tiled", [(128, 16, 40, 0), (128, 16, 40, 1), (256, 128, 128, 0)])
+def test_mrope_kv_prefill(hd, sec0, sec1, tiled):
     Hq, Hkv, nseq, Tp, ctx = 4, 2, 2, 128, 256
     rows = nseq * Tp
-    W = (Hq + 2 * Hkv) * 128
+    W = (Hq + 2 * Hkv) * hd
     qkv = randbf(rows, W, seed=28)
     g = torch.Generator().manual_seed(29)
     pos3 = torch.randint(0, 300, (3, rows), generator=g, dtype=torch.int32)
-    cos_t, sin_t = _rope_tables(512)
-    Q = torch.zeros(rows, Hq * 128, dtype=torch.bfloat16, device=DEV)
-    Kc = torch.zeros(nseq, Hkv, ctx, 128, dtype=torch.bfloat16, device=DEV)
-    VT = torch.zeros(nseq, Hkv, 128, ctx, dtype=torch.bfloat16, device=DEV)
+    cos_t, sin_t = _rope_tables(512, hd=hd)
+    Q = torch.zeros(rows, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    Kc = torch.zeros(nseq, Hkv, ctx, hd, dtype=torch.bfloat16, device=DEV)
+    VT = torch.zeros(nseq, Hkv, hd, ctx, dtype=torch.bfloat16, device=DEV)
     pos_d, cos_d, sin_d = pos3.to(DEV), cos_t.to(DEV), sin_t.to(DEV)
     rc = lib().hwocr_mrope_kv_prefill(p(qkv), p(Q), p(Kc), p(VT), p(pos_d), p(cos_d), p(sin_d),
-                                      rows, Tp, Hq, Hkv, 16, 40, Hkv * ctx * 128, ctx * 128, Hkv * 128 * ctx, 128 * ctx,
-                                      ctx, tiled, st())
+                                      rows, Tp, Hq, Hkv, sec0, sec1, Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx,
+                                      ctx, hd, tiled, st())
     assert rc == 0
     sync()
     if tiled:
         Kc, VT = untile_k(Kc), untile_v(VT)
     x = qkv.float().cpu()
-    qw = _mrope_ref(x[:, : Hq * 128].view(rows, Hq, 128), pos3, cos_t, sin_t, 16, 40)
-    kw = _mrope_ref(x[:, Hq * 128: (Hq + Hkv) * 128].view(rows, Hkv, 128), pos3, cos_t, sin_t, 16, 40)
-    assert torch.equal(Q.float().cpu().view(rows, Hq, 128), qw), "M-RoPE q must reproduce the bf16 rounding chain"
-    assert torch.equal(Kc[:, :, :Tp].float().cpu(), kw.view(nseq, Tp, Hkv, 128).permute(0, 2, 1, 3))
-    vw = qkv.cpu()[:, (Hq + Hkv) * 128:].view(nseq, Tp, Hkv, 128).permute(0, 2, 3, 1)
+    qw = _mrope_ref(x[:, : Hq * hd].view(rows, Hq, hd), pos3, cos_t, sin_t, sec0, sec1)
+    kw = _mrope_ref(x[:, Hq * hd: (Hq + Hkv) * hd].view(rows, Hkv, hd), pos3, cos_t, sin_t, sec0, sec1)
+    assert torch.equal(Q.float().cpu().view(rows, Hq, hd), qw), "M-RoPE q must reproduce the bf16 rounding chain"
+    assert torch.equal(Kc[:, :, :Tp].float().cpu(), kw.view(nseq, Tp, Hkv, hd).permute(0, 2, 1, 3))
+    vw = qkv.cpu()[:, (Hq + Hkv) * hd:].view(nseq, Tp, Hkv, hd).permute(0, 2, 3, 1)
     assert torch.equal(VT[:, :, :, :Tp].cpu(), vw)
 
 
-@pytest.mark.parametrize("tiled", [0, 1])
-def test_decode_qkv_finish(tiled):
-    Hq, Hkv, B, ctx, nslab = 12, 2, 5, 256, 3
-    W = (Hq + 2 * Hkv) * 128
+@pytest.mark.parametrize("hd,Hq,Hkv,sec0,sec1,tiled", [(128, 12, 2, 16, 40, 0), (128, 12, 2, 16, 40, 1), (256, 8, 1, 128, 128, 0)])
+def test_decode_qkv_finish(hd, Hq, Hkv, sec0, sec1, tiled):
+    B, ctx, nslab = 5, 256, 3
+    W = (Hq + 2 * Hkv) * hd
     slabs = torch.randn(nslab, B, W, device=DEV)
     bias = randbf(W, seed=30)
     lens = torch.tensor([1, 10, 200, 256, 77], dtype=torch.int32)
     delta = torch.tensor([0, -5, 3, -100, 40], dtype=torch.int32)
-    cos_t, sin_t = _rope_tables(512)
-    Q = torch.zeros(B, Hq * 128, dtype=torch.bfloat16, device=DEV)
-    Kc = torch.zeros(B, Hkv, ctx, 128, dtype=torch.bfloat16, device=DEV)
-    VT = torch.zeros(B, Hkv, 128, ctx, dtype=torch.bfloat16, device=DEV)
+    cos_t, sin_t = _rope_tables(512, hd=hd)
+    Q = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    Kc = torch.zeros(B, Hkv, ctx, hd, dtype=torch.bfloat16, device=DEV)
+    VT = torch.zeros(B, Hkv, hd, ctx, dtype=torch.bfloat16, device=DEV)
     lens_d, delta_d, cos_d, sin_d = lens.to(DEV), delta.to(DEV), cos_t.to(DEV), sin_t.to(DEV)
     rc = lib().hwocr_decode_qkv_finish(p(slabs), nslab, B * W, p(bias), p(Q), p(Kc), p(VT), p(lens_d),
                                        p(delta_d), p(cos_d), p(sin_d), B, Hq, Hkv,
-                                       Hkv * ctx * 128, ctx * 128, Hkv * 128 * ctx, 128 * ctx, ctx, tiled, st())
+                                       Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd, tiled, st())
     assert rc == 0
     sync()
     if tiled:
@@ -440,14 +459,14 @@ def test_decode_qkv_finish(tiled):
     row = rbf((slabs.sum(0) + bias.float()).cpu())
     pos = (lens - 1 + delta)
     pos3 = pos.unsqueeze(0).expand(3, B)
-    qw = _mrope_ref(row[:, : Hq * 128].view(B, Hq, 128), pos3, cos_t, sin_t, 16, 40)
-    kw = _mrope_ref(row[:, Hq * 128: (Hq + Hkv) * 128].view(B, Hkv, 128), pos3, cos_t, sin_t, 16, 40)
+    qw = _mrope_ref(row[:, : Hq * hd].view(B, Hq, hd), pos3, cos_t, sin_t, sec0, sec1)
+    kw = _mrope_ref(row[:, Hq * hd: (Hq + Hkv) * hd].view(B, Hkv, hd), pos3, cos_t, sin_t, sec0, sec1)
     # slab summation order differs from torch.sum by fp32 rounding only -> 1 bf16 ulp
-    assert_close_bf16(Q.view(B, Hq, 128).cpu(), qw, ulps=1.0, atol=1e-3, what="decode q")
+    assert_close_bf16(Q.view(B, Hq, hd).cpu(), qw, ulps=1.0, atol=1e-3, what="decode q")
     for b in range(B):
         slot = int(lens[b]) - 1
         assert_close_bf16(Kc[b, :, slot].cpu(), kw[b], ulps=1.0, atol=1e-3, what="decode k")
-        assert_close_bf16(VT[b, :, :, slot].cpu(), row[b, (Hq + Hkv) * 128:].view(Hkv, 128), ulps=1.0, atol=1e-3,
+        assert_close_bf16(VT[b, :, :, slot].cpu(), row[b, (Hq + Hkv) * hd:].view(Hkv, hd), ulps=1.0, atol=1e-3,
                           what="decode v")
         assert (Kc[b].float().abs().sum(-1) != 0).sum() == Hkv  # exactly one slot written per kv head
 

@@ -439,9 +439,10 @@ def make_model(family: str = "qwen2_vl") -> None:
         os.chmod(os.path.join(GOLD, fn), 0o644)
 
 
-# PaliGemma (BASELINE config 4): SigLIP head_dim 72 and Gemma head_dim 256 as in the 3B checkpoint, everything else tiny
+# PaliGemma (BASELINE config 4): SigLIP head_dim 72 (8 heads: width 576 is a multiple of 64 like the real 1152), an MLP width
+# that is not (600, real 4304) and Gemma head_dim 256 as in the 3B checkpoint, everything else tiny
 TINYPG = dict(
-    vision=dict(hidden_size=144, intermediate_size=160, num_hidden_layers=2, num_attention_heads=2, image_size=56,
+    vision=dict(hidden_size=576, intermediate_size=600, num_hidden_layers=2, num_attention_heads=8, image_size=56,
                 patch_size=14, projection_dim=256, vision_use_head=False, num_image_tokens=16),
     text=dict(model_type="gemma", vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
               num_attention_heads=2, num_key_value_heads=1, head_dim=256, max_position_embeddings=1024,
