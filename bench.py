@@ -34,14 +34,17 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-WORKLOAD_NAMES = {"qwen2-vl-2b": "Qwen2-VL-2B", "qwen2.5-vl-7b": "Qwen2.5-VL-7B / olmOCR-2-7B", "qwen2.5-vl-3b": "Qwen2.5-VL-3B"}
+WORKLOAD_NAMES = {"paligemma-3b": "PaliGemma-3B (SigLIP-So400m 896 + Gemma-2B, bf16)", "qwen2-vl-2b": "Qwen2-VL-2B", "qwen2.5-vl-7b": "Qwen2.5-VL-7B / olmOCR-2-7B", "qwen2.5-vl-3b": "Qwen2.5-VL-3B"}
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0
 
 
 def synthetic_prompt(cfg, n_img: int) -> np.ndarray:
-    """14 prefix ids + <vision_start> + image placeholders + <vision_end> + 16 suffix ids."""
+    """14 prefix ids + <vision_start> + image placeholders + <vision_end> + 16 suffix ids.
+    PaliGemma: image placeholders + <bos> + 16 prompt ids (its processor's layout)."""
     rng = np.random.default_rng(0)
+    if cfg.family == "paligemma":
+        return np.asarray([cfg.image_token_id] * n_img + [cfg.bos_id] + rng.integers(3, 1000, size=16).tolist(), np.int32)
     pre = rng.integers(0, 1000, size=14).tolist()
     suf = rng.integers(0, 1000, size=16).tolist()
     return np.asarray(pre + [cfg.vision_start_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_id] + suf, np.int32)
@@ -60,9 +63,10 @@ def build_inputs(cfg, n_pages: int, seed0: int, reads_per_page: int, side: int, 
     for p in range(n_pages):
         img = Image.fromarray(synth.make_page(seed0 + p, side, side), "RGB")
         for s in strategies:
-            arr = imageproc.prepare_page(preprocess.apply_strategy(img, s, quiet=True), cfg.patch_size, cfg.merge,
-                                         config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS)
-            pages.append(torch.from_numpy(arr).to(device))
+            pre = preprocess.apply_strategy(img, s, quiet=True)
+            arr = (imageproc.prepare_square(pre, cfg.image_size) if cfg.family == "paligemma" else
+                   imageproc.prepare_page(pre, cfg.patch_size, cfg.merge, config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS))
+            pages.append(torch.from_numpy(arr.copy()).to(device))
     host_s = time.perf_counter() - t0
     n_img = (pages[0].shape[0] // cfg.patch_size) * (pages[0].shape[1] // cfg.patch_size) // cfg.merge ** 2
     prompts = [synthetic_prompt(cfg, n_img)] * len(pages)
@@ -80,6 +84,9 @@ def cpu_baseline(cfg, side: int, n_out: int, reads_per_page: int) -> dict:
     from handwritten_ocr_amd.compat import config
     from oracle import image_ref, text_ref
     from oracle.qwen2vl_ref import Qwen2VLRef, RefConfig
+
+    if cfg.family == "paligemma":
+        return cpu_baseline_paligemma(cfg, side, n_out, reads_per_page)
 
     # the GPU box grants ~16 host cores per GPU; more torch threads than that only oversubscribe
     try:
@@ -160,6 +167,82 @@ def cpu_baseline(cfg, side: int, n_out: int, reads_per_page: int) -> dict:
                         "prefill_per_layer": dp, "decode_step_1layer": t_d1, "decode_step_per_layer": dd, "strings": t_str}}
 
 
+def cpu_baseline_paligemma(cfg, side: int, n_out: int, reads_per_page: int) -> dict:
+    """As cpu_baseline, for the SigLIP + Gemma path (oracle/paligemma_ref.py): 1 and 2 layers of each stack at full
+    widths, extrapolated linearly in depth; the prefix prefill is bidirectional over 4096 image tokens + the prompt."""
+    import dataclasses
+
+    from PIL import Image
+
+    from handwritten_ocr_amd import engine, imageproc, synth
+    from oracle import text_ref
+    from oracle.paligemma_ref import PaliGemmaRef, PaliRefConfig
+
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(torch.get_num_threads(), avail, 16))
+    torch.set_num_threads(threads)
+    sd = engine.random_state_dict(dataclasses.replace(cfg, depth=2, layers=2), seed=0, device="cpu")
+
+    def ref(depth, layers):
+        rc = PaliRefConfig(v_layers=depth, v_hidden=cfg.embed_dim, v_heads=cfg.num_heads, v_inter=cfg.vit_inter,
+                           patch_size=cfg.patch_size, image_size=cfg.image_size, hidden=cfg.hidden, layers=layers,
+                           q_heads=cfg.q_heads, kv_heads=cfg.kv_heads, head_dim=cfg.head_dim, inter=cfg.inter, vocab=cfg.vocab,
+                           rope_theta=cfg.rope_theta, image_token_id=cfg.image_token_id, eos_ids=tuple(cfg.eos_ids), pad_id=cfg.pad_id)
+        return PaliGemmaRef(rc, sd)
+
+    def timed(fn):
+        t = time.perf_counter()
+        out = fn()
+        return time.perf_counter() - t, out
+
+    img = Image.fromarray(synth.make_page(0, side, side), "RGB")
+    lut = imageproc.pixel_lut((0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+
+    def pixels():
+        page = imageproc.prepare_square(img, cfg.image_size)
+        return torch.from_numpy(np.stack([lut[c][page[:, :, c]] for c in range(3)]))
+
+    t_img, pv = timed(pixels)
+    with torch.no_grad():
+        t_v1, emb = timed(lambda: ref(1, 1).vision(pv))
+        t_v2, _ = timed(lambda: ref(2, 1).vision(pv))
+        ids = torch.from_numpy(synthetic_prompt(cfg, emb.shape[0])).long()
+        T = len(ids)
+        x = ref(1, 1).embed(torch.where(ids == cfg.image_token_id, torch.zeros_like(ids), ids))
+        pos = torch.arange(T) + 1
+
+        def prefill(layers):
+            r = ref(1, layers)
+            cache = [None] * layers
+            return r, cache, r.lm_head(r.decoder(x, pos, cache, bidirectional=True)[-1:])
+
+        t_p1, (r1, c1, _) = timed(lambda: prefill(1))
+        t_p2, (r2, c2, _) = timed(lambda: prefill(2))
+        n_dec = 4
+        t_d1, _ = timed(lambda: [r1.step(5, c1) for _ in range(n_dec)])
+        t_d2, _ = timed(lambda: [r2.step(5, c2) for _ in range(n_dec)])
+    t_d1, t_d2 = t_d1 / n_dec, t_d2 / n_dec
+    dv, dp, dd = max(t_v2 - t_v1, 0.0), max(t_p2 - t_p1, 0.0), max(t_d2 - t_d1, 0.0)
+    t_read = t_img + t_v1 + (cfg.depth - 1) * dv + t_p1 + (cfg.layers - 1) * dp + (n_out - 1) * (t_d1 + (cfg.layers - 1) * dd)
+    rng = np.random.default_rng(1)
+    words = ["".join(chr(97 + int(c)) for c in rng.integers(0, 26, size=int(rng.integers(2, 9)))) for _ in range(260)]
+    texts = [" ".join(words)] + [" ".join(w if rng.random() > 0.1 else w[::-1] for w in words) for _ in range(2)]
+    t_str, _ = timed(lambda: (text_ref.compare_versions(texts[0], texts[1]), text_ref.merge_versions(texts)))
+    t_page = reads_per_page * t_read + t_str
+    return {"value": 1.0 / t_page, "unit": "pages/s", "cores": threads, "kind": "port",
+            "sample": (f"oracle/paligemma_ref.py (torch CPU bf16 restatement of the HF PaliGemma path) at full {cfg.name} widths on "
+                       f"one {side}x{side} page resized to {cfg.image_size}^2: SigLIP tower / bidirectional prefix prefill (T={T}) / "
+                       f"decode step timed with 1 and 2 layers and extrapolated linearly to {cfg.depth}/{cfg.layers} layers; "
+                       f"{n_dec} decode steps scaled to {n_out - 1}; compare+merge of three {len(texts[0])}-char reads; "
+                       f"x{reads_per_page} serial reads per page as nodes.py:86-110"),
+            "seconds_per_page": t_page,
+            "parts_s": {"image_processor": t_img, "vision_1layer": t_v1, "vision_per_layer": dv, "prefill_1layer": t_p1,
+                        "prefill_per_layer": dp, "decode_step_1layer": t_d1, "decode_step_per_layer": dd, "strings": t_str}}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +272,10 @@ def main() -> None:
     cfg = engine.preset(args.model)
     n_reads = args.pages * args.reads
     sd = engine.random_state_dict(cfg, seed=0, device=dev)
-    eng = engine.ReadEngine(cfg, sd, max_reads=n_reads, ctx=2048, device=str(dev), vit_batch=args.vit_batch,
+    # KV-cache length: prompt (image tokens + ~32) + generated tokens, rounded up
+    n_img_tokens = (cfg.image_size // cfg.patch_size) ** 2 if cfg.family == "paligemma" else 1296
+    ctx = 2048 if n_img_tokens + 64 + args.new_tokens <= 2048 else (n_img_tokens + 128 + args.new_tokens + 63) // 64 * 64
+    eng = engine.ReadEngine(cfg, sd, max_reads=n_reads, ctx=ctx, device=str(dev), vit_batch=args.vit_batch,
                             prefill_batch=args.prefill_batch)
     del sd
     eng.collect_timings = True
@@ -243,9 +329,10 @@ def main() -> None:
     T = len(prompts[0])
     dec_ms = mean("decode_ms") / max(1, args.new_tokens - 1)
     # decoder bytes per step: all layer weights + LM head (tied) + KV of every read at its mean context
-    per_layer = (cfg.q_heads + 2 * cfg.kv_heads) * 128 * cfg.hidden + cfg.q_heads * 128 * cfg.hidden + 3 * cfg.inter * cfg.hidden
+    hd = cfg.head_dim
+    per_layer = (cfg.q_heads + 2 * cfg.kv_heads) * hd * cfg.hidden + cfg.q_heads * hd * cfg.hidden + 3 * cfg.inter * cfg.hidden
     w_bytes = 2.0 * (cfg.layers * per_layer + cfg.vocab * cfg.hidden)
-    kv_bytes = n_reads * cfg.layers * 2 * cfg.kv_heads * 128 * 2 * (T + args.new_tokens / 2)
+    kv_bytes = n_reads * cfg.layers * 2 * cfg.kv_heads * hd * 2 * (T + args.new_tokens / 2)
     # HBM-side traffic of the dominant kernel: not measurable in-process — taken from the committed summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (tools/pmc_summary.py, corrections stated there)
     traffic = None

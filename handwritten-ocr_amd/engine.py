@@ -167,9 +167,9 @@ def random_state_dict(cfg: ModelConfig, seed: int = 0, device="cuda", std: float
     HD = cfg.head_dim
     if cfg.family == "paligemma":
         v = "model.vision_tower."
-        g = cfg.image_size // cfg.patch_size
+        side = cfg.image_size // cfg.patch_size
         sd[v + "embeddings.patch_embedding.weight"], sd[v + "embeddings.patch_embedding.bias"] = rn(D, 3, cfg.patch_size, cfg.patch_size), rn(D)
-        sd[v + "embeddings.position_embedding.weight"] = rn(g * g, D)
+        sd[v + "embeddings.position_embedding.weight"] = rn(side * side, D)
         for l in range(cfg.depth):
             b = f"{v}encoder.layers.{l}."
             for n in ("layer_norm1", "layer_norm2"):
@@ -262,6 +262,23 @@ def load_checkpoint_dir(path: str, device="cuda") -> tuple[ModelConfig, dict]:
     vc = hf.get("vision_config", {})
     tc = hf.get("text_config", hf)
     rope = tc.get("rope_parameters") or tc.get("rope_scaling") or {}
+    if hf.get("model_type") == "paligemma":
+        rope = tc.get("rope_parameters") or {}
+        cfg = ModelConfig(
+            name=os.path.basename(path.rstrip("/")), family="paligemma", depth=vc.get("num_hidden_layers", 27),
+            embed_dim=vc.get("hidden_size", 1152), num_heads=vc.get("num_attention_heads", 16),
+            vit_inter=vc.get("intermediate_size", 4304), patch_size=vc.get("patch_size", 14), merge=1, tps=1,
+            image_size=vc.get("image_size", 896), head_dim=tc.get("head_dim", 256), hidden=tc.get("hidden_size", 2048),
+            layers=tc.get("num_hidden_layers", 18), q_heads=tc.get("num_attention_heads", 8),
+            kv_heads=tc.get("num_key_value_heads", 1), inter=tc.get("intermediate_size", 16384),
+            vocab=tc.get("vocab_size", 257216), rope_theta=rope.get("rope_theta", tc.get("rope_theta", 10000.0)),
+            eps=tc.get("rms_norm_eps", 1e-6), tie=True, image_token_id=hf.get("image_token_id", 257152),
+            eos_ids=(hf.get("eos_token_id", 1),), pad_id=hf.get("pad_token_id", 0), bos_id=hf.get("bos_token_id", 2))
+        sd = {}
+        for fn in sorted(os.listdir(path)):
+            if fn.endswith(".safetensors"):
+                sd.update(load_file(os.path.join(path, fn)))
+        return cfg, {k: v.to(device=device, dtype=torch.bfloat16) for k, v in normalize_keys(sd).items()}
     v25 = hf.get("model_type") == "qwen2_5_vl" or vc.get("model_type") == "qwen2_5_vl_vision" or "fullatt_block_indexes" in vc
     tower = dict(family="qwen2_5_vl", embed_dim=vc.get("hidden_size", 1280), vit_inter=vc.get("intermediate_size", 3420),
                  window_size=vc.get("window_size", 112), fullatt=tuple(vc.get("fullatt_block_indexes", (7, 15, 23, 31)))) \

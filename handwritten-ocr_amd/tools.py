@@ -12,7 +12,8 @@ HWOCR_KEEP_RESIDENT=0 — the reference drops them after every node so Ollama fi
 288 GB MI355X only buys a checkpoint reload per re-read.  `run_ocr_batch` is the batched entry the reference lacks.
 
 Model selection: HWOCR_MODEL = a checkpoint directory (config.json + *.safetensors [+ tokenizer.json]) or a preset
-name ("qwen2-vl-2b", "qwen2.5-vl-7b" = "olmocr-2-7b", "qwen2.5-vl-3b", "small", "tiny", "tiny25"); presets are
+name ("qwen2-vl-2b", "qwen2.5-vl-7b" = "olmocr-2-7b", "qwen2.5-vl-3b", "paligemma-3b", "small", "tiny", "tiny25",
+"tinypg"); presets are
 random-init because no checkpoint is reachable offline.
 """
 from __future__ import annotations
