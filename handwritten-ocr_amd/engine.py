@@ -272,7 +272,8 @@ def load_checkpoint_dir(path: str, device="cuda") -> tuple[ModelConfig, dict]:
             layers=tc.get("num_hidden_layers", 18), q_heads=tc.get("num_attention_heads", 8),
             kv_heads=tc.get("num_key_value_heads", 1), inter=tc.get("intermediate_size", 16384),
             vocab=tc.get("vocab_size", 257216), rope_theta=rope.get("rope_theta", tc.get("rope_theta", 10000.0)),
-            eps=tc.get("rms_norm_eps", 1e-6), tie=True, image_token_id=hf.get("image_token_id", 257152),
+            eps=tc.get("rms_norm_eps", 1e-6), tie=True,
+            image_token_id=hf.get("image_token_index", hf.get("image_token_id", 257152)),  # PaliGemma serialises `_index`
             eos_ids=(hf.get("eos_token_id", 1),), pad_id=hf.get("pad_token_id", 0), bos_id=hf.get("bos_token_id", 2))
         sd = {}
         for fn in sorted(os.listdir(path)):
