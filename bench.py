@@ -248,7 +248,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pages", type=int, default=42, help="pages per step per GPU (x3 reads in flight, <= 256 reads)")
+    ap.add_argument("--pages", type=int, default=84, help="pages per step per GPU (x3 reads in flight, <= 256 reads)")
     ap.add_argument("--reads", type=int, default=3)
     ap.add_argument("--new-tokens", type=int, default=512)
     ap.add_argument("--side", type=int, default=1024)

@@ -443,9 +443,9 @@ extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias,
     return HWOCR_EINVAL;
   if (epi != EPI_PARTIAL && splitk != 1) return HWOCR_EINVAL;
   if ((epi == EPI_SWIGLU || epi == EPI_GEGLU) && bias) return HWOCR_EINVAL;
-  // up to 128 rows over fragment-tiled weights: the LDS-DMA streaming kernel (gemm_stream.hip)
+  // fragment-tiled weights: the LDS-DMA streaming kernel (gemm_stream.hip)
   static const bool use_stream = [] { const char* e = getenv("HWOCR_GEMM_STREAM"); return !e || atoi(e) != 0; }();
-  if (use_stream && w_tiled && Bsz <= 128 && (K % 64) == 0) {
+  if (use_stream && w_tiled && Bsz <= 256 && (K % 64) == 0) {
     const int ktiles = K / 64, per = (ktiles + splitk - 1) / splitk;
     // a plain linear over more than one round of 16-tile groups (the LM head) re-stages x once per group: the older
     // kernel's 128-row groups do that cheaper (LM head 2B: 90 us against 104)

@@ -25,13 +25,14 @@
 // bytes-into-CU ceiling but re-read weight tiles for idle waves: 3.3 TB/s; dropped.
 // Epilogues as gemm_skinny: PARTIAL fp32 split-K slabs, LINEAR (+bias), SWIGLU on interleaved gate/up tile pairs.
 #include "gemm_common.cuh"
+#include <cstdlib>
 
 using namespace gemm;
 
 namespace {
 
 constexpr int WG_TILES = 16;               // weight tiles per workgroup
-constexpr int NSTAGE = 3;
+constexpr int WAVES = 16;
 constexpr int WBYTES = WG_TILES * 2048;    // one K tile (64) of 16 weight tiles' fragments
 
 __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of this wave's DMA instructions in flight
@@ -43,35 +44,41 @@ __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of t
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
   }
 }
 
-// MT: 16-row activation tiles (Bsz <= 16 MT).  WAVES x NTW = 16 weight tiles.  grid = (tile groups, K slices).
-template <int MT, int EPI, int WAVES>
+// MT: 16-row activation tiles (Bsz <= 16 MT).  16 waves = MSPLIT (row halves) x 16/MSPLIT (tile groups): a wave multiplies
+// MT/MSPLIT row tiles by MSPLIT weight tiles.  MSPLIT = 2 halves the x fragments every wave has to read from LDS (all 16
+// waves reading the whole x tile is 288 KB of ds_read per K tile at 128 rows - as long as the DMA of that K tile takes).
+// Staging is independent of that split: wave w brings in weight tile w of the group and x rows {8(w + 16e)}.
+// grid = (tile groups, K slices).
+template <int MT, int EPI, int MSPLIT>
 __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
-  constexpr int NTW = WG_TILES / WAVES;             // weight tiles per wave
+  constexpr int NWN = WAVES / MSPLIT;               // waves along N
+  constexpr int NTW = WG_TILES / NWN;               // weight tiles per wave (= MSPLIT)
+  constexpr int MTW = MT / MSPLIT;                  // row tiles per wave
   constexpr int XFR = 2 * MT;                       // x DMA instructions (8 rows x 128 B = 1 KiB each) per K tile
   constexpr int XPW = (XFR + WAVES - 1) / WAVES;    // staged per wave
   constexpr int XBYTES = XFR * 1024;
   constexpr int STAGE = XBYTES + WBYTES;
+  constexpr int NSTAGE = 3 * STAGE <= 160 * 1024 ? 3 : 2;
+  constexpr int DIST = NSTAGE - 1;                  // K tiles in flight ahead of the one being multiplied
+  static_assert(MT % MSPLIT == 0 && (MSPLIT == 1 || MSPLIT == 2), "row tiles split evenly over the wave rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
+  const int wn = w % NWN, wm = w / NWN;
 
-  // ---- this workgroup's weight tiles [t0, t1) (SwiGLU: whole gate/up pairs) and K tiles [kt0, kt0 + nk)
+  // ---- this workgroup's weight tiles [t0, t1) (gated epilogues: whole gate/up pairs) and K tiles [kt0, kt0 + nk)
   constexpr int UNIT = is_glu<EPI> ? 2 : 1;
   const int units = (a.N >> 4) / UNIT;
   const int t0 = (int)((long)blockIdx.x * units / gridDim.x) * UNIT;
   const int t1 = (int)((long)(blockIdx.x + 1) * units / gridDim.x) * UNIT;
-  const int my0 = t0 + w * NTW;
-  const int mine = max(0, min(NTW, t1 - my0));     // wave-uniform
+  const int my0 = t0 + wn * NTW;                    // first tile this wave multiplies
+  const int mine = max(0, min(NTW, t1 - my0));      // wave-uniform
+  const bool stage_w = t0 + w < t1;                 // this wave stages tile t0 + w
   const int kt0 = blockIdx.y * a.ktiles_per_slice;
   const int nk = min(a.ktiles_per_slice, (a.K >> 6) - kt0);
 
@@ -83,9 +90,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
     const int f = w + WAVES * e;
     xsrc[e] = a.X + (size_t)min(8 * f + (lane >> 3), a.Bsz - 1) * a.ldx + (size_t)kt0 * 64 + 8 * ((lane & 7) ^ (lane >> 3));
   }
-  const bf16* wsrc = a.W + ((size_t)my0 * (a.K >> 5) + (size_t)kt0 * 2) * 512 + lane * 8;  // + j*(K/32)*512 + t*1024 + h*512
-  const size_t wtile = (size_t)(a.K >> 5) * 512;
-  const int n_dma = (XFR > w ? (XFR - w + WAVES - 1) / WAVES : 0) + 2 * mine;  // DMA instructions of this wave per stage
+  const bf16* wsrc = a.W + ((size_t)(t0 + w) * (a.K >> 5) + (size_t)kt0 * 2) * 512 + lane * 8;  // + t*1024 + h*512
+  const int n_dma = (XFR > w ? (XFR - w + WAVES - 1) / WAVES : 0) + (stage_w ? 2 : 0);  // DMA instructions per stage
 
   auto issue = [&](int t) {
     char* st = smem + (t % NSTAGE) * STAGE;
@@ -93,63 +99,63 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
     for (int e = 0; e < XPW; ++e)
       if (w + WAVES * e < XFR)
         __builtin_amdgcn_global_load_lds((const void*)(xsrc[e] + t * 64), LDS_PTR(st + (w + WAVES * e) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-      if (j < mine) {
-        const bf16* s = wsrc + j * wtile + (size_t)t * 1024;
-        char* d = st + XBYTES + (w * NTW + j) * 2048;
-        __builtin_amdgcn_global_load_lds((const void*)s, LDS_PTR(d), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const void*)(s + 512), LDS_PTR(d + 1024), 16, 0, 0);
-      }
+    if (stage_w) {
+      const bf16* s = wsrc + (size_t)t * 1024;
+      char* d = st + XBYTES + w * 2048;
+      __builtin_amdgcn_global_load_lds((const void*)s, LDS_PTR(d), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)(s + 512), LDS_PTR(d + 1024), 16, 0, 0);
+    }
   };
 
-  f32x4 acc[NTW][MT];
+  f32x4 acc[NTW][MTW];
 #pragma unroll
   for (int j = 0; j < NTW; ++j)
 #pragma unroll
-    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MTW; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nk > 0) issue(0);
-  if (nk > 1) issue(1);
+#pragma unroll
+  for (int d = 0; d < DIST; ++d)
+    if (d < nk) issue(d);
   for (int t = 0; t < nk; ++t) {
-    wait_dma(t + 1 < nk ? n_dma : 0);     // K tile t of this wave has landed; t+1 may still fly
-    __builtin_amdgcn_s_barrier();         // ... of every wave; and every wave is done reading K tile t-1
+    wait_dma(min(DIST - 1, nk - 1 - t) * n_dma);  // K tile t of this wave has landed; later ones may still fly
+    __builtin_amdgcn_s_barrier();                  // ... of every wave; and every wave is done reading K tile t-1
     __builtin_amdgcn_sched_barrier(0);
-    if (t + 2 < nk) issue(t + 2);         // into the slot K tile t-1 occupied
+    if (t + DIST < nk) issue(t + DIST);            // into the slot K tile t-1 occupied
     const char* st = smem + (t % NSTAGE) * STAGE;
-    bf16x8 xf[MT][2], wf[NTW][2];
+    bf16x8 xf[MTW][2], wf[NTW][2];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) xf[i][h] = *(const bf16x8*)(st + (16 * i + c) * 128 + (((4 * h + q) ^ (c & 7)) << 4));
+      for (int h = 0; h < 2; ++h)
+        xf[i][h] = *(const bf16x8*)(st + (16 * (wm * MTW + i) + c) * 128 + (((4 * h + q) ^ (c & 7)) << 4));
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) wf[j][h] = *(const bf16x8*)(st + XBYTES + (w * NTW + j) * 2048 + h * 1024 + lane * 16);
+      for (int h = 0; h < 2; ++h) wf[j][h] = *(const bf16x8*)(st + XBYTES + (wn * NTW + j) * 2048 + h * 1024 + lane * 16);
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
       if (j < mine) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
+          for (int i = 0; i < MTW; ++i)
             acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][h], xf[i][h], acc[j][i], 0, 0, 0);
       }
   }
 
-  // ---- epilogue: lane (c,q): acc[j][i][r] = out[16 i + c][16 (my0 + j) + 4 q + r]
+  // ---- epilogue: lane (c,q): acc[j][i][r] = out[16 (wm MTW + i) + c][16 (my0 + j) + 4 q + r]
   if constexpr (is_glu<EPI> && NTW == 1) {
     // gate tile in the even wave, up tile in the odd one: the up accumulators cross through the (now idle) ring
     __builtin_amdgcn_s_barrier();  // every wave is done reading the last K tile
-    float* xch = (float*)smem + (w >> 1) * (MT * 256);
+    float* xch = (float*)smem + (w >> 1) * (MTW * 256);
     if (w & 1) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) *(f32x4*)(xch + (i * 64 + lane) * 4) = acc[0][i];
+      for (int i = 0; i < MTW; ++i) *(f32x4*)(xch + (i * 64 + lane) * 4) = acc[0][i];
     }
     __builtin_amdgcn_s_barrier();
     if (!(w & 1) && mine > 0) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
+      for (int i = 0; i < MTW; ++i) {
         const int m = 16 * i + c;
         const f32x4 up = *(const f32x4*)(xch + (i * 64 + lane) * 4);
         if (m < a.Bsz) {
@@ -163,8 +169,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
     return;
   }
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = 16 * i + c;
+  for (int i = 0; i < MTW; ++i) {
+    const int m = 16 * (wm * MTW + i) + c;
     if (m >= a.Bsz) continue;
     if constexpr (is_glu<EPI>) {
 #pragma unroll
@@ -201,25 +207,130 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
   }
 }
 
-template <int MT, int EPI>
-void launch_one(const StreamArgs& a, dim3 grid, hipStream_t st) {
-  constexpr int WAVES = 16;
-  constexpr int LDS = NSTAGE * (2 * MT * 1024 + WBYTES);
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<MT, EPI, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    done = true;
+// 129..256 rows: the x tile of a 64-wide K tile alone is 32 KiB and only two stages would fit, i.e. nothing in flight
+// while a stage is awaited (measured: 4.2 us per K tile).  This variant walks K in 32-wide tiles instead: a stage is 16
+// x fragments + 16 weight fragments of 1 KiB (one DMA instruction of each per wave, both already in MFMA operand order:
+// lane (c, q) of x fragment i <- x[16 i + c][32 t + 8 q ..]), four stages, three K tiles in flight.  Waves: 2 row halves
+// x 8 tile pairs, as MSPLIT = 2 above.
+template <int EPI>
+__global__ __launch_bounds__(64 * WAVES) void gemm_stream256_kernel(StreamArgs a) {
+  constexpr int MT = 16, MTW = 8, NTW = 2, NWN = 8;
+  constexpr int STAGE = (MT + WG_TILES) * 1024, NSTAGE = 4, DIST = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int wn = w % NWN, wm = w / NWN;
+  constexpr int UNIT = is_glu<EPI> ? 2 : 1;
+  const int units = (a.N >> 4) / UNIT;
+  const int t0 = (int)((long)blockIdx.x * units / gridDim.x) * UNIT;
+  const int t1 = (int)((long)(blockIdx.x + 1) * units / gridDim.x) * UNIT;
+  const int my0 = t0 + wn * NTW;
+  const int mine = max(0, min(NTW, t1 - my0));
+  const bool stage_w = t0 + w < t1;
+  const int kt0 = blockIdx.y * a.ktiles_per_slice * 2;                       // in 32-wide tiles
+  const int nk = min(a.ktiles_per_slice * 2, (a.K >> 5) - kt0);
+  const bf16* xsrc = a.X + (size_t)min(16 * w + c, a.Bsz - 1) * a.ldx + (size_t)kt0 * 32 + 8 * q;  // x fragment w
+  const bf16* wsrc = a.W + ((size_t)(t0 + w) * (a.K >> 5) + kt0) * 512 + lane * 8;
+  const int n_dma = 1 + (stage_w ? 1 : 0);
+  auto issue = [&](int t) {
+    char* st = smem + (t % NSTAGE) * STAGE;
+    __builtin_amdgcn_global_load_lds((const void*)(xsrc + t * 32), LDS_PTR(st + w * 1024), 16, 0, 0);
+    if (stage_w) __builtin_amdgcn_global_load_lds((const void*)(wsrc + (size_t)t * 512), LDS_PTR(st + (MT + w) * 1024), 16, 0, 0);
+  };
+  f32x4 acc[NTW][MTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < DIST; ++d)
+    if (d < nk) issue(d);
+  for (int t = 0; t < nk; ++t) {
+    wait_dma(min(DIST - 1, nk - 1 - t) * n_dma);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + DIST < nk) issue(t + DIST);
+    const char* st = smem + (t % NSTAGE) * STAGE;
+    bf16x8 xf[MTW], wf[NTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) xf[i] = *(const bf16x8*)(st + (wm * MTW + i) * 1024 + lane * 16);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) wf[j] = *(const bf16x8*)(st + (MT + wn * NTW + j) * 1024 + lane * 16);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+      if (j < mine) {
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+      }
   }
-  hipLaunchKernelGGL((gemm_stream_kernel<MT, EPI, WAVES>), grid, dim3(64 * WAVES), LDS, st, a);
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int m = 16 * (wm * MTW + i) + c;
+    if (m >= a.Bsz) continue;
+    if constexpr (is_glu<EPI>) {
+      if (mine > 0) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(glu_gate<EPI>(rbf(acc[0][i][r]))) * rbf(acc[1][i][r]));
+        *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + 8 * my0 + 4 * q) = o;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+        if (j < mine) {
+          const int n = 16 * (my0 + j) + 4 * q;
+          if constexpr (EPI == EPI_PARTIAL) {
+            *(f32x4*)((float*)a.out + ((size_t)blockIdx.y * a.Bsz + m) * a.ldo + n) = acc[j][i];
+          } else {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r];
+            if (a.bias) {
+              const bf16x4 bb = *(const bf16x4*)(a.bias + n);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += bf2f(bb[r]);
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(v[r]);
+            *(bf16x4*)((bf16*)a.out + (size_t)m * a.ldo + n) = o;
+          }
+        }
+    }
+  }
 }
 
-template <int MT>
+template <int EPI>
+void launch256(const StreamArgs& a, dim3 grid, hipStream_t st) {
+  constexpr int LDS = 4 * (16 + WG_TILES) * 1024;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)gemm_stream256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    done = true;
+  }
+  hipLaunchKernelGGL((gemm_stream256_kernel<EPI>), grid, dim3(64 * WAVES), LDS, st, a);
+}
+
+template <int MT, int EPI, int MSPLIT>
+void launch_one(const StreamArgs& a, dim3 grid, hipStream_t st) {
+  constexpr int STAGE = 2 * MT * 1024 + WBYTES;
+  constexpr int LDS = (3 * STAGE <= 160 * 1024 ? 3 : 2) * STAGE;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<MT, EPI, MSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    done = true;
+  }
+  hipLaunchKernelGGL((gemm_stream_kernel<MT, EPI, MSPLIT>), grid, dim3(64 * WAVES), LDS, st, a);
+}
+
+template <int MT, int MSPLIT>
 int launch_mt(const StreamArgs& a, int epi, dim3 grid, hipStream_t st) {
   switch (epi) {
-    case EPI_LINEAR: launch_one<MT, EPI_LINEAR>(a, grid, st); break;
-    case EPI_SWIGLU: launch_one<MT, EPI_SWIGLU>(a, grid, st); break;
-    case EPI_GEGLU: launch_one<MT, EPI_GEGLU>(a, grid, st); break;
-    case EPI_PARTIAL: launch_one<MT, EPI_PARTIAL>(a, grid, st); break;
+    case EPI_LINEAR: launch_one<MT, EPI_LINEAR, MSPLIT>(a, grid, st); break;
+    case EPI_SWIGLU: launch_one<MT, EPI_SWIGLU, MSPLIT>(a, grid, st); break;
+    case EPI_GEGLU: launch_one<MT, EPI_GEGLU, MSPLIT>(a, grid, st); break;
+    case EPI_PARTIAL: launch_one<MT, EPI_PARTIAL, MSPLIT>(a, grid, st); break;
     default: return HWOCR_EINVAL;
   }
   return hwocr_launch_status();
@@ -227,9 +338,9 @@ int launch_mt(const StreamArgs& a, int epi, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
-// Shapes this kernel takes: fragment-tiled W, Bsz <= 128, K % 64 == 0, every K slice non-empty.
+// Shapes this kernel takes: fragment-tiled W, Bsz <= 256, K % 64 == 0, every K slice non-empty.
 int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
-  if (a.Bsz < 1 || a.Bsz > 128 || (a.K % 64) || (a.N % 16) || splitk < 1) return HWOCR_EINVAL;
+  if (a.Bsz < 1 || a.Bsz > 256 || (a.K % 64) || (a.N % 16) || splitk < 1) return HWOCR_EINVAL;
   const int ktiles = a.K / 64;
   a.ktiles_per_slice = (ktiles + splitk - 1) / splitk;
   if ((splitk - 1) * a.ktiles_per_slice >= ktiles) return HWOCR_EINVAL;  // an empty slice would leave its slab unwritten
@@ -246,8 +357,17 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
   while ((units + groups - 1) / groups > per_wg) ++groups;
   const dim3 grid(groups, splitk);
   const int mt = (a.Bsz + 15) / 16;
-  if (mt <= 1) return launch_mt<1>(a, epi, grid, stream);
-  if (mt <= 2) return launch_mt<2>(a, epi, grid, stream);
-  if (mt <= 4) return launch_mt<4>(a, epi, grid, stream);
-  return launch_mt<8>(a, epi, grid, stream);
+  static const int split8 = [] { const char* e = getenv("HWOCR_STREAM_MSPLIT"); return e ? atoi(e) : 2; }();
+  if (mt <= 1) return launch_mt<1, 1>(a, epi, grid, stream);
+  if (mt <= 2) return launch_mt<2, 1>(a, epi, grid, stream);
+  if (mt <= 4) return launch_mt<4, 1>(a, epi, grid, stream);
+  if (mt <= 8) return split8 == 2 ? launch_mt<8, 2>(a, epi, grid, stream) : launch_mt<8, 1>(a, epi, grid, stream);
+  switch (epi) {
+    case EPI_LINEAR: launch256<EPI_LINEAR>(a, grid, stream); break;
+    case EPI_SWIGLU: launch256<EPI_SWIGLU>(a, grid, stream); break;
+    case EPI_GEGLU: launch256<EPI_GEGLU>(a, grid, stream); break;
+    case EPI_PARTIAL: launch256<EPI_PARTIAL>(a, grid, stream); break;
+    default: return HWOCR_EINVAL;
+  }
+  return hwocr_launch_status();
 }

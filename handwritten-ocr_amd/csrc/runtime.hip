@@ -181,7 +181,7 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   const int Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
   const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
   const float scale = 1.0f / sqrtf((float)HD);
-  bool stream = nseq <= 128 && (Hd % 64) == 0 && (OW % 64) == 0 && (m->inter % 64) == 0;
+  bool stream = (Hd % 64) == 0 && (OW % 64) == 0 && (m->inter % 64) == 0;
   for (int l = 0; l < m->layers && stream; ++l) stream = m->L[l].qkv_wt && m->L[l].o_wt && m->L[l].down_wt;
   const int s_qkv = stream ? pick_splitk_stream(Hd, QW) : pick_splitk(Hd, QW, 400);
   const int s_o = stream ? pick_splitk_stream(OW, Hd) : pick_splitk(OW, Hd, 400);
