@@ -449,7 +449,7 @@ extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias,
     const int ktiles = K / 64, per = (ktiles + splitk - 1) / splitk;
     // a plain linear over more than one round of 16-tile groups (the LM head) re-stages x once per group: the older
     // kernel's 128-row groups do that cheaper (LM head 2B: 90 us against 104)
-    const bool many_rounds = epi == EPI_LINEAR && N / 16 > 16 * 256;
+    const bool many_rounds = epi == EPI_LINEAR && N / 16 > 16 * 256 && Bsz <= 128;  // (at 129+ rows the older kernel is slower)
     if ((splitk - 1) * per < ktiles && !many_rounds)
       return hwocr_gemm_stream(StreamArgs{(const bf16*)X, (const bf16*)W, (const bf16*)bias, out, Bsz, N, K, ldx, ldo, 0},
                                epi, splitk, stream);

@@ -56,7 +56,7 @@ def _load_ocr_model():
         sd = engine.random_state_dict(cfg, seed=int(os.environ.get("HWOCR_SEED", "0")))
         tok = tokenizer.ByteTokenizer(cfg, fold_unknown=True)
     cfg.min_pixels, cfg.max_pixels = config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS
-    _ocr_model = engine.ReadEngine(cfg, sd, max_reads=int(os.environ.get("HWOCR_MAX_READS", "96")),
+    _ocr_model = engine.ReadEngine(cfg, sd, max_reads=int(os.environ.get("HWOCR_MAX_READS", "252")),
                                    ctx=int(os.environ.get("HWOCR_CTX", "4096")))
     _ocr_processor = tokenizer.Processor(cfg, tok)
     print("  [ocr] Model loaded.")
