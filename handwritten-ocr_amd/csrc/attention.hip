@@ -256,8 +256,15 @@ int launch_prefill(const PrefillArgs& a, int nseg, int heads, int max_len, hipSt
 constexpr int V80_K0 = 64 * 128, V80_K1 = 64 * 32, V80_VT = 88 * 128;
 constexpr int V80_STAGE = V80_K0 + V80_K1 + V80_VT;  // 21504 B
 
-__global__ __launch_bounds__(256, 3) void attn_vit80_kernel(PrefillArgs a) {
-  constexpr int HD = 80;
+// WAVES x 32 queries per workgroup.  Every workgroup streams the whole K / V^T of its (head, page) through LDS, so the
+// bytes entering the CUs per query fall with the queries per workgroup: at 4 waves (128 queries, 3 workgroups per CU) a
+// 12-page launch staged 13.5 GB in 1.8 ms = 7.5 TB/s - the chip's into-CU ceiling, not the matrix or vector pipes, was
+// the bound.  12 waves (384 queries, one workgroup per CU, the same 3 waves per SIMD) stage a third of that.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void attn_vit80_kernel(PrefillArgs a) {
+  constexpr int HD = 80, NT = 64 * WAVES;
+  constexpr int NSTG = 2;                   // LDS stages (a third one for the lone 12-wave workgroup measured slower: 3186 vs 3022 ms of vision per step)
+  constexpr int DIST = NSTG - 1;            // K/V tiles in flight ahead of the one being multiplied
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages
   // 1-D grid of qblocks x (head, page) pairs.  Consecutive block ids go to different XCDs, so give every XCD whole
   // (head, page) pairs: all query blocks that re-read one K / V^T then share one L2 (measured before: 5x the unique
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256, 3) void attn_vit80_kernel(PrefillArgs a) {
     }
     seg = pair / a.heads;
     h = pair % a.heads;
-    q0 = qb * 128;
+    q0 = qb * (32 * WAVES);
   }
   const int len = a.lens[seg];
   if (q0 >= len) return;
@@ -296,35 +303,36 @@ __global__ __launch_bounds__(256, 3) void attn_vit80_kernel(PrefillArgs a) {
     for (int s = 0; s < 5; ++s) qf[s] = *(const bf16x8*)(qrow + 16 * s);
   }
   // V^T rows 80..87 of both stages: row 80 = 1.0, the rest 0 (never touched by the DMA)
-  for (int i = tid; i < 2 * 8 * 64; i += 256) {
+  for (int i = tid; i < NSTG * 8 * 64; i += NT) {
     const int stg = i >> 9, rr = (i >> 6) & 7, col = i & 63;
     ((bf16*)(smem + stg * V80_STAGE + V80_K0 + V80_K1 + (80 + rr) * 128))[col] = (bf16)(rr == 0 ? 1.0f : 0.0f);
   }
 
-  // DMA plan per tile: 20 instructions, 5 per wave:  K0: 8 (2 per wave), K1: 2 (waves 0,1), V^T: 10 (2,2,3,3)
+  // DMA plan per tile: 20 instructions of 1 KiB dealt round-robin to the waves: K d 0..63 (8: 8 key rows each),
+  // K d 64..79 (2: 32 key rows each), V^T (10: 8 d rows each)
   const int nt = (len + 63) >> 6;
   auto stage_tile = [&](int t) {
     const int j0 = t * 64;
-    char* st = smem + (t & 1) * V80_STAGE;
+    char* st = smem + (t % NSTG) * V80_STAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {  // K d 0..63: 8 rows per instruction
-      const int row = 8 * (2 * w + i) + (lane >> 3);
-      const int lc = (lane & 7) ^ ((row >> 1) & 7);
-      __builtin_amdgcn_global_load_lds((const void*)(Kp + (long)min(j0 + row, len - 1) * a.k_row + lc * 8),
-                                       LDS_PTR(st + (2 * w + i) * 1024), 16, 0, 0);
-    }
-    if (w < 2) {  // K d 64..79: 32 rows per instruction
-      const int row = 32 * w + (lane >> 1);
-      const int lc = (lane & 1) ^ ((row >> 3) & 1);
-      __builtin_amdgcn_global_load_lds((const void*)(Kp + (long)min(j0 + row, len - 1) * a.k_row + 64 + lc * 8),
-                                       LDS_PTR(st + V80_K0 + w * 1024), 16, 0, 0);
-    }
-    const int v0 = w < 2 ? 2 * w : 4 + 3 * (w - 2), vn = w < 2 ? 2 : 3;  // V^T: 8 d rows per instruction
-    for (int i = 0; i < vn; ++i) {
-      const int d = 8 * (v0 + i) + (lane >> 3);
-      const int lc = (lane & 7) ^ ((d >> 1) & 7);
-      __builtin_amdgcn_global_load_lds((const void*)(Vp + (long)d * a.v_row + j0 + lc * 8),
-                                       LDS_PTR(st + V80_K0 + V80_K1 + (v0 + i) * 1024), 16, 0, 0);
+    for (int e = 0; e < (20 + WAVES - 1) / WAVES; ++e) {
+      const int k = w + WAVES * e;  // wave-uniform
+      if (k < 8) {
+        const int row = 8 * k + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((const void*)(Kp + (long)min(j0 + row, len - 1) * a.k_row + lc * 8),
+                                         LDS_PTR(st + k * 1024), 16, 0, 0);
+      } else if (k < 10) {
+        const int row = 32 * (k - 8) + (lane >> 1);
+        const int lc = (lane & 1) ^ ((row >> 3) & 1);
+        __builtin_amdgcn_global_load_lds((const void*)(Kp + (long)min(j0 + row, len - 1) * a.k_row + 64 + lc * 8),
+                                         LDS_PTR(st + V80_K0 + (k - 8) * 1024), 16, 0, 0);
+      } else if (k < 20) {
+        const int d = 8 * (k - 10) + (lane >> 3);
+        const int lc = (lane & 7) ^ ((d >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((const void*)(Vp + (long)d * a.v_row + j0 + lc * 8),
+                                         LDS_PTR(st + V80_K0 + V80_K1 + (k - 10) * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -335,17 +343,28 @@ __global__ __launch_bounds__(256, 3) void attn_vit80_kernel(PrefillArgs a) {
     for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
   float m = NEG_BIG;
 
-  stage_tile(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // this wave's DMA instructions per tile: tasks w, w + WAVES, .. < 20
+  const int n_dma = (20 - w + WAVES - 1) / WAVES;
+  auto wait_tiles_in_flight = [&](int tiles) {  // counted: leave `tiles` later tiles of this wave in flight
+    const int pend = tiles * n_dma;
+    if (pend <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (pend == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // WAVES == 4: 5 per tile
+  };
+#pragma unroll
+  for (int d = 0; d < DIST; ++d)
+    if (d < nt) stage_tile(d);
+  wait_tiles_in_flight(min(DIST - 1, nt - 1));
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int j0 = t * 64;
-    char* st = smem + (t & 1) * V80_STAGE;
-    if (t + 1 < nt) stage_tile(t + 1);
+    char* st = smem + (t % NSTG) * V80_STAGE;
+    if (t + DIST < nt) stage_tile(t + DIST);  // into the slot tile t-1 occupied (every wave passed the barrier after it)
     if (j0 + 64 > len) {
       // tail tile: keys past the segment must contribute 0 * finite.  Their scores are masked below; their V^T columns
       // are whatever the buffer holds, so clear them in LDS (one extra barrier, last tile only).
-      for (int i = tid; i < 80 * 64; i += 256) {
+      for (int i = tid; i < 80 * 64; i += NT) {
         const int d = i >> 6, col = i & 63;
         if (j0 + col >= len) {
           const int ch = (col >> 3) ^ ((d >> 1) & 7);
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(256, 3) void attn_vit80_kernel(PrefillArgs a) {
           const bf16x8 vf = *(const bf16x8*)(vb + row * 128 + (((kt * 4 + s2 * 2 + hh) ^ ((row >> 1) & 7)) << 4));
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kt][s2], o[d], 0, 0, 0);
         }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_tiles_in_flight(min(DIST - 1, nt - 2 - t));  // tile t+1 has landed
     __syncthreads();
   }
 
@@ -440,12 +459,23 @@ __global__ __launch_bounds__(256, 3) void attn_vit80_kernel(PrefillArgs a) {
 }
 
 int launch_vit80(const PrefillArgs& a, int nseg, int heads, int max_len, hipStream_t st) {
-  constexpr int LDS = 2 * V80_STAGE;
+  // long segments (pages: 5184 tokens): 12 waves; short ones keep 128-query workgroups so the grid still fills the chip
+  static const int forced = [] { const char* e = getenv("HWOCR_VIT80_WAVES"); return e ? atoi(e) : 0; }();
+  const int waves = forced ? forced : (max_len >= 1536 ? 12 : 4);
   PrefillArgs b = a;
   b.heads = heads;
   b.nseg = nseg;
-  b.qblocks = (max_len + 127) / 128;
-  hipLaunchKernelGGL(attn_vit80_kernel, dim3(b.qblocks * heads * nseg), dim3(256), LDS, st, b);
+  b.qblocks = (max_len + 32 * waves - 1) / (32 * waves);
+  if (waves == 12) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)attn_vit80_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V80_STAGE);
+      done = true;
+    }
+    hipLaunchKernelGGL(attn_vit80_kernel<12>, dim3(b.qblocks * heads * nseg), dim3(768), 2 * V80_STAGE, st, b);
+  } else {
+    hipLaunchKernelGGL(attn_vit80_kernel<4>, dim3(b.qblocks * heads * nseg), dim3(256), 2 * V80_STAGE, st, b);
+  }
   return hwocr_launch_status();
 }
 

@@ -203,6 +203,33 @@ def test_attn_prefill(hd, Hq, Hkv, causal, tiled):
     assert torch.isfinite(out.float()).all()
 
 
+def test_attn_vit80_long_segments():
+    """Page-length segments take the 12-wave (384 queries per workgroup) form of the head_dim-80 kernel: ragged lengths
+    around its block size, one of them shorter than a single block."""
+    hd, heads = 80, 2
+    lens = [2000, 1537, 383, 769]
+    nseg, Lp = len(lens), 2048
+    q = randbf(nseg, heads, Lp, hd, seed=41)
+    k = randbf(nseg, heads, Lp, hd, seed=42)
+    v = randbf(nseg, heads, Lp, hd, seed=43)
+    vt = v.transpose(2, 3).contiguous()
+    for s_, n in enumerate(lens):
+        vt[s_, :, :, n:] = float("nan")
+        k[s_, :, n:, :] = 1e4
+    out = torch.zeros(nseg, Lp, heads * hd, dtype=torch.bfloat16, device=DEV)
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    scale = hd ** -0.5
+    rc = lib().hwocr_attn_prefill(p(q), p(k), p(vt), p(out), p(lens_d), nseg, heads, 1, hd, max(lens), 0,
+                                  heads * Lp * hd, Lp * hd, hd, heads * Lp * hd, Lp * hd, hd,
+                                  heads * hd * Lp, hd * Lp, Lp, Lp * heads * hd, heads * hd, scale, 0, st())
+    assert rc == 0
+    sync()
+    for s_, n in enumerate(lens):
+        want = _sdpa_ref(q[s_, :, :n].float(), k[s_, :, :n].float(), v[s_, :, :n].float(), False, scale)
+        assert_close_bf16(out[s_, :n].view(n, heads, hd), want, ulps=4.0, atol=4e-3, what=f"attn_vit80 12-wave seg {s_}")
+    assert torch.isfinite(out.float()).all()
+
+
 @pytest.mark.parametrize("hd,heads", [(80, 4), (32, 2)])
 def test_attn_varlen_windows(hd, heads):
     """Ragged windows packed on one row axis (Qwen2.5-VL windowed layers): starts are multiples of 4 rows only."""
