@@ -12,6 +12,9 @@ Per page the reference's four output files are written with the same names and f
 (transcribe.py:76-101, trace.py:56-70): `<stem>_transcription.txt`, `_trace.json`, `_trace_summary.txt`, `_eval.json`.
 The critic / editor / re-OCR loop needs the LLM agents, which are out of scope: pass callables through `agents=` to run
 the full graph (`compat.nodes.run_graph`); without them a page stops after `initial_ocr` with status "initial_ocr".
+With agents, every DISTINCT preprocessing strategy of every page is read in the same batched pass: a later
+`reocr` node (nodes.py:239-302: next unused strategy, one more read, after a model reload in the reference) is then
+answered from that pass — same node code, same text, no second trip through the engine.
 
 Multi-GPU: one process per GPU (`torchrun`), pages dealt round-robin (`shard.shard`), every rank writes its own pages'
 files; token streams are additionally gathered to rank 0 by `tools.run_ocr_batch` callers that need them (bench.py).
@@ -41,10 +44,11 @@ def list_images(folder: Path) -> list[Path]:
     return sorted(f for f in Path(folder).iterdir() if f.suffix.lower() in IMAGE_EXTENSIONS)
 
 
-def _speculative_strategies(strategies: list) -> list:
-    """The (at most three) distinct strategies node_initial_ocr can touch, in its order (nodes.py:86-110, dedup :36-39)."""
+def _speculative_strategies(strategies: list, every: bool = False) -> list:
+    """The (at most three) distinct strategies node_initial_ocr can touch, in its order (nodes.py:86-110, dedup :36-39);
+    `every`: all distinct strategies, i.e. also those node_reocr would pick next (nodes.py:246-251)."""
     out, seen = [], set()
-    for s in (strategies[:3] if strategies else ["original"]):
+    for s in ((strategies if every else strategies[:3]) if strategies else ["original"]):
         label = nodes._strategy_label(s)
         if label not in seen:
             seen.add(label)
@@ -52,9 +56,40 @@ def _speculative_strategies(strategies: list) -> list:
     return out
 
 
-def initial_ocr_batched(image_paths: list, params: dict | None = None, cfg=config, workers: int = 8) -> list[dict]:
-    """States after `initial_ocr` for every page, computed with ONE batched engine pass over all reads."""
-    strategies = _speculative_strategies(list(cfg.PREPROCESSING_STRATEGIES))
+def _replay_readers(strategies: list, texts: list, fallback=None):
+    """(preprocess_image, run_ocr) stand-ins that answer one page's reads from the finished batch, printing what the
+    real ones print; strategies outside the batch go to `fallback` = the real (preprocess_image, run_ocr) pair."""
+    labels = [nodes._strategy_label(s) for s in strategies]
+    by_token: dict = {}
+
+    def replay_preprocess(image_path, strategy):
+        label = nodes._strategy_label(strategy)
+        if label not in labels:
+            if fallback is None:
+                raise KeyError(f"strategy {label!r} was not part of the batched pass")
+            return fallback[0](image_path, strategy)
+        token = f"{image_path}#{label}"
+        by_token[token] = texts[labels.index(label)]
+        if preprocess.steps_of(strategy) not in (["original"], []):
+            print(f"  [preprocess] Applying {preprocess.label_of(strategy)}...")
+        return token
+
+    def replay_run_ocr(token, params=None):
+        if token not in by_token:
+            return fallback[1](token, params)
+        print(f"  [ocr] Running OCR on {Path(token.split('#')[0]).name}...")
+        print(f"  [ocr] Done ({len(by_token[token])} chars)")
+        return by_token[token]
+
+    return replay_preprocess, replay_run_ocr
+
+
+def initial_ocr_batched(image_paths: list, params: dict | None = None, cfg=config, workers: int = 8,
+                        speculate_reocr: bool = False, reads_out: list | None = None) -> list[dict]:
+    """States after `initial_ocr` for every page, computed with ONE batched engine pass over all reads.
+    `speculate_reocr`: also read the strategies a later `reocr` node would use; `reads_out` (a list) receives, per page,
+    (strategies, texts) of everything that was read."""
+    strategies = _speculative_strategies(list(cfg.PREPROCESSING_STRATEGIES), every=speculate_reocr)
 
     def prepare(path):
         img = Image.open(path)
@@ -68,22 +103,10 @@ def initial_ocr_batched(image_paths: list, params: dict | None = None, cfg=confi
     states = []
     k = len(strategies)
     for p, path in enumerate(image_paths):
-        by_token = {}
-
-        def fake_preprocess(image_path, strategy, _p=p, _by=by_token):
-            label = nodes._strategy_label(strategy)
-            idx = [nodes._strategy_label(s) for s in strategies].index(label)
-            token = f"{image_path}#{label}"
-            _by[token] = texts[_p * k + idx]
-            if preprocess.steps_of(strategy) not in (["original"], []):
-                print(f"  [preprocess] Applying {preprocess.label_of(strategy)}...")
-            return token
-
-        def fake_run_ocr(token, params=None, _by=by_token):
-            print(f"  [ocr] Running OCR on {Path(token.split('#')[0]).name}...")
-            print(f"  [ocr] Done ({len(_by[token])} chars)")
-            return _by[token]
-
+        page_texts = texts[p * k: (p + 1) * k]
+        fake_preprocess, fake_run_ocr = _replay_readers(strategies, page_texts)
+        if reads_out is not None:
+            reads_out.append((strategies, page_texts))
         state = new_state(str(path), cfg)
         saved = (nodes.preprocess_image, nodes.run_ocr, nodes.unload_ocr_model)
         nodes.preprocess_image, nodes.run_ocr, nodes.unload_ocr_model = fake_preprocess, fake_run_ocr, (lambda: None)
@@ -127,15 +150,22 @@ def transcribe_folder(images: list, output_dir: Path, ground_truth_dir: Path | N
     rank, _, world = shard.init_from_env()
     mine = shard.shard([Path(p) for p in images], rank, world)
     sink = io.StringIO() if quiet else None
+    reads: list = []
     with contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext():
-        states = initial_ocr_batched([str(p) for p in mine], params)
+        states = initial_ocr_batched([str(p) for p in mine], params, speculate_reocr=bool(agents), reads_out=reads)
     outs = []
-    for state in states:
+    for state, (strategies, page_texts) in zip(states, reads):
         if agents:
             nodes.run_critic, nodes.run_editor = agents["critic"], agents["editor"]
             nodes.run_arbitrator = agents.get("arbitrator")
-            with contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext():
-                state = nodes.run_graph_after_initial(state)
+            # re-OCR rounds read the strategies that were prefetched in the batched pass; anything else goes to the engine
+            saved = (nodes.preprocess_image, nodes.run_ocr)
+            nodes.preprocess_image, nodes.run_ocr = _replay_readers(strategies, page_texts, fallback=saved)
+            try:
+                with contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext():
+                    state = nodes.run_graph_after_initial(state)
+            finally:
+                nodes.preprocess_image, nodes.run_ocr = saved
         else:
             state["status"], state["reason"] = "initial_ocr", "no_agents"
         gt = None

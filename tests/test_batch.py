@@ -80,3 +80,46 @@ def test_folder_outputs(tmp_path, monkeypatch):
 def test_cli_rejects_missing_input(tmp_path):
     with pytest.raises(SystemExit):
         batch.main([str(tmp_path / "nope")])
+
+
+def test_reocr_rounds_are_answered_from_the_batched_pass(tmp_path, monkeypatch):
+    """With agents, every distinct strategy is read in the one batched pass and the `reocr` node — the same
+    node code — gets its read from there: the engine is entered exactly once, and the result equals the serial graph."""
+    paths = _pages(tmp_path, 2)
+    distinct = batch._speculative_strategies(list(config.PREPROCESSING_STRATEGIES), every=True)
+    labels = [nodes._strategy_label(s) for s in distinct]
+    assert len(labels) > 3, "the reference config has more distinct strategies than initial_ocr uses"
+    calls = []
+
+    def fake_batch(images, params=None):
+        calls.append(len(images))
+        return [f"page {i // len(labels)} read with {labels[i % len(labels)]} words more words" for i in range(len(images))]
+
+    class Arb:
+        def __init__(self, versions):
+            self.final_text, self.confidence = versions[-1]["text"].upper(), 77
+            self.decisions, self.uncertain_segments = [], []
+
+        def model_dump(self):
+            return {"final_text": self.final_text, "confidence": self.confidence}
+
+    def critic(text, previous_critique=None):
+        # first look: ask for a re-read; after it: accept
+        if text.isupper():
+            return {"overall_confidence": 95, "verdict": "accept", "issues": []}
+        return {"overall_confidence": 40, "verdict": "needs_reocr", "issues": []}
+
+    agents = {"critic": critic, "editor": lambda t, c: {"corrected_text": t, "changes": []}, "arbitrator": Arb}
+    monkeypatch.setattr(tools, "run_ocr_batch", fake_batch)
+    monkeypatch.setattr(nodes, "run_ocr", lambda *a, **k: pytest.fail("re-OCR must not enter the engine again"))
+    monkeypatch.setattr(nodes, "unload_ocr_model", lambda: None)
+    outs = batch.transcribe_folder(batch.list_images(tmp_path), tmp_path / "out", agents=agents, quiet=True)
+    assert calls == [2 * len(labels)]
+    for i, o in enumerate(outs):
+        text = o.read_text()
+        # initial_ocr consumed strategies 0..2 at most; the re-read is the next unused one, upper-cased by the scripted arbitrator
+        ev = json.loads((tmp_path / "out" / f"page{i:02d}_trace.json").read_text())
+        used = [e["metrics"]["strategy"] for e in ev if e["action"] == "ocr"]
+        assert used == labels[: len(used)] and len(used) >= 3
+        assert text == f"page {i} read with {used[-1]} words more words".upper()
+        assert [e["action"] for e in ev][-3:] == ["arbitrate", "critique", "accept"]
