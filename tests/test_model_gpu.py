@@ -137,6 +137,29 @@ def test_eos_stops_a_read(eng):
     assert out == free[: first + 1]
 
 
+def test_eos_in_graph_mode_and_mixed_lengths(eng):
+    """Graph-replayed decode with reads that stop at different steps: a finished read pads on in lockstep and its output
+    ends at its EOS; the loop leaves early once every read has stopped."""
+    g = tiny_case("bf16")
+    pages = [_page(eng, g, c) for c in ("a", "b")]
+    prompts = [g[f"{c}.input_ids"].numpy() for c in ("a", "b")]
+    n = 40
+    free = eng.generate(pages, prompts, max_new=n, min_new=n, use_graph=True)
+    # pick an EOS that read 0 emits early and read 1 later (or never)
+    eos = next(t for t in free[0][2:12] if t not in free[1][: free[0].index(t) + 1])
+    old = eng.cfg.eos_ids
+    eng.cfg.eos_ids = (eos,)
+    try:
+        out = eng.generate(pages, prompts, max_new=n, min_new=0, use_graph=True)
+        eager = eng.generate(pages, prompts, max_new=n, min_new=0, use_graph=False)
+    finally:
+        eng.cfg.eos_ids = old
+    assert out == eager
+    assert out[0] == free[0][: free[0].index(eos) + 1]
+    want1 = free[1][: free[1].index(eos) + 1] if eos in free[1] else free[1]
+    assert out[1] == want1
+
+
 def test_drop_in_tools_surface(tmp_path, monkeypatch, capsys):
     """run_ocr / run_ocr_batch / unload_ocr_model with the reference's signatures and prints, through the compat node."""
     from handwritten_ocr_amd import tools
