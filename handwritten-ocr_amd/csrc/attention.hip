@@ -60,9 +60,12 @@ __global__ __launch_bounds__(256, HD > 128 ? 1 : 2) void attn_prefill_kernel(Pre
 
   const int qi = q0 + 32 * w + r;  // this lane's query column
   const int rk = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);  // r with bits 2 and 3 swapped
-  bf16x8 qf[NS];
-  {
-    const bf16* qrow = Qp + (long)min(qi, len - 1) * a.q_row + 8 * hh;
+  // query fragments: in registers, except for 256-wide heads (64 VGPRs that push the kernel into spills): those re-read
+  // their 16-byte pieces from L1/L2 inside the score loop
+  constexpr bool QREG = HD <= 128;
+  const bf16* qrow = Qp + (long)min(qi, len - 1) * a.q_row + 8 * hh;
+  bf16x8 qf[QREG ? NS : 1];
+  if constexpr (QREG) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = *(const bf16x8*)(qrow + 16 * s);
   }
@@ -146,8 +149,9 @@ __global__ __launch_bounds__(256, HD > 128 ? 1 : 2) void attn_prefill_kernel(Pre
     for (int s = 0; s < NS; ++s) {
       const bf16x8 k0 = *(const bf16x8*)(kb + rk * KS + (16 * s + 8 * hh) * 2);
       const bf16x8 k1 = *(const bf16x8*)(kb + (32 + rk) * KS + (16 * s + 8 * hh) * 2);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[s], s1, 0, 0, 0);
+      const bf16x8 qs = QREG ? qf[QREG ? s : 0] : *(const bf16x8*)(qrow + 16 * s);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qs, s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qs, s1, 0, 0, 0);
     }
     const bool need_mask = (j0 + 64 > len) || (CAUSAL && (j0 + 63 > q0 + 32 * w));
     if (need_mask) {
