@@ -76,7 +76,8 @@ class DecWs(C.Structure):
 
 class GenState(C.Structure):
     _fields_ = [(n, P) for n in ("cur_ids", "lens", "n_gen", "finished", "out_tokens", "rope_delta")] + [
-        ("max_new", I), ("min_new", I), ("n_eos", I), ("pad_id", I), ("eos", I * 4)]
+        ("max_new", I), ("min_new", I), ("n_eos", I), ("pad_id", I), ("eos", I * 4), ("seen", P), ("seen_ld", I),
+        ("rep_penalty", F)]
 
 
 _HIP_SIGS = {
@@ -95,7 +96,7 @@ _HIP_SIGS = {
     "hwocr_mrope_kv_prefill": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, I, I, P], I),
     "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, I, I, P], I),
     "hwocr_embed_splice": ([P, P, P, P, P, I, I, F, P], I),
-    "hwocr_argmax_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P], I),
+    "hwocr_argmax_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P, I, F, P], I),
     "hwocr_vit_forward": ([C.POINTER(Vit), C.POINTER(VitWs), P, I, I, I, I, C.POINTER(VitLayout), P, P], I),
     "hwocr_prefill": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), P, P, P, P, P, P,
                        I, I, I, I, P], I),

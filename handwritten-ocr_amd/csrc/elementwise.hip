@@ -470,6 +470,7 @@ struct SelectArgs {
   const bf16* logits; int ldl, V;
   int* cur_ids; int* lens; int* n_gen; int* finished; int* out_tokens; int max_new, min_new;
   int eos[4]; int n_eos; int pad_id;
+  unsigned* seen; int seen_ld; float rep_penalty;  // bitmap [nseq][seen_ld words] of ids in prompt + output so far, or NULL
 };
 // One workgroup of 16 waves per read: a row is V x 2 B (300 KB at V = 151936) and only `nseq` CUs take part, so what
 // matters is loads in flight per CU — 4 independent 16-byte loads per thread per trip (256 threads, one load per trip:
@@ -485,11 +486,25 @@ __global__ __launch_bounds__(ARG_THREADS) void argmax_advance_kernel(SelectArgs 
   float best = -INFINITY;
   int bi = 0x7fffffff;
   const int nch = a.V / 8;
+  // RepetitionPenaltyLogitsProcessor (HF generation/logits_process.py: score < 0 ? score * p : score / p for every id
+  // already in input_ids), on the fp32 copy of the logits like every processor
+  // The token fed to produce these logits (cur_ids: the previous pick, or the teacher-forced one the host wrote) joins the
+  // bitmap first; the prompt's ids were put there by the host, and the call that follows a prefill has n_gen == 0.
+  if (a.seen) {
+    if (tid == 0 && a.n_gen[b] > 0 && !a.finished[b]) {
+      const int t = a.cur_ids[b];
+      if (t >= 0 && t < a.V) a.seen[(long)b * a.seen_ld + (t >> 5)] |= 1u << (t & 31);
+    }
+    __syncthreads();
+  }
+  const unsigned* seen = a.seen ? a.seen + (long)b * a.seen_ld : nullptr;
   auto take = [&](const bf16x8& v, int ch) {
+    const unsigned bits = seen ? (seen[ch >> 2] >> ((ch & 3) * 8)) & 0xffu : 0u;  // the 8 ids of this chunk
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float x = bf2f(v[e]);
       const int idx = ch * 8 + e;
+      if ((bits >> e) & 1u) x = x < 0.f ? x * a.rep_penalty : x / a.rep_penalty;
       if (suppress)
         for (int k = 0; k < a.n_eos; ++k)
           if (idx == a.eos[k]) x = -INFINITY;
@@ -630,11 +645,13 @@ extern "C" int hwocr_embed_splice(const int* ids, const int* img_row, const void
 
 extern "C" int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_ids, int* lens, int* n_gen,
                                     int* finished, int* out_tokens, int max_new, int min_new, const int* eos,
-                                    int n_eos, int pad_id, hipStream_t stream) {
+                                    int n_eos, int pad_id, unsigned* seen, int seen_ld, float rep_penalty,
+                                    hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseq <= 0 || V % 8 || ldl % 8 || n_eos < 0 || n_eos > 4) return HWOCR_EINVAL;
+  if (seen && (seen_ld * 32 < V || !(rep_penalty > 0.f))) return HWOCR_EINVAL;
   SelectArgs a{(const bf16*)logits, ldl, V, cur_ids, lens, n_gen, finished, out_tokens, max_new, min_new,
-               {0, 0, 0, 0}, n_eos, pad_id};
+               {0, 0, 0, 0}, n_eos, pad_id, (seen && rep_penalty != 1.0f) ? seen : nullptr, seen_ld, rep_penalty};
   for (int k = 0; k < n_eos; ++k) a.eos[k] = eos[k];
   hipLaunchKernelGGL(argmax_advance_kernel, dim3(nseq), dim3(ARG_THREADS), 0, stream, a);
   return hwocr_launch_status();

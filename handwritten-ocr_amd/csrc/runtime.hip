@@ -168,7 +168,8 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
                           Hd, m->vocab, HWOCR_EPI_LINEAR, 1, m->lm_head_t != nullptr, st));
   CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids + seq0, gs->lens + seq0,
                              gs->n_gen + seq0, gs->finished + seq0, gs->out_tokens + (long)seq0 * gs->max_new,
-                             gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, st));
+                             gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id,
+                             gs->seen ? gs->seen + (long)seq0 * gs->seen_ld : nullptr, gs->seen_ld, gs->rep_penalty, st));
   return HWOCR_OK;
 }
 
@@ -215,7 +216,8 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head_t ? m->lm_head_t : m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd,
                           Hd, m->vocab, HWOCR_EPI_LINEAR, 1, m->lm_head_t != nullptr, st));
   CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished,
-                             gs->out_tokens, gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, st));
+                             gs->out_tokens, gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, gs->seen, gs->seen_ld,
+                             gs->rep_penalty, st));
   return HWOCR_OK;
 }
 

@@ -68,6 +68,9 @@ class ModelConfig:
     im_end_id: int = 151645
     eos_ids: tuple = (151645, 151643)
     pad_id: int = 151643
+    # generation defaults of the checkpoint (generation_config.json): only the deterministic part is implemented — the
+    # repetition penalty; temperatures of the Qwen-VL checkpoints (1e-6 .. 0.01 with top_k 1) make sampling the argmax
+    repetition_penalty: float = 1.0
     # processor bounds (ocr_agent/config.py:17-18)
     min_pixels: int = 256 * 256
     max_pixels: int = 1024 * 1024
@@ -294,6 +297,10 @@ def load_checkpoint_dir(path: str, device="cuda") -> tuple[ModelConfig, dict]:
         tie=bool(hf.get("tie_word_embeddings", tc.get("tie_word_embeddings", False))),
         image_token_id=hf.get("image_token_id", 151655), vision_start_id=hf.get("vision_start_token_id", 151652),
         vision_end_id=hf.get("vision_end_token_id", 151653))
+    gen_path = os.path.join(path, "generation_config.json")
+    if os.path.exists(gen_path):
+        with open(gen_path) as f:
+            cfg.repetition_penalty = float(json.load(f).get("repetition_penalty") or 1.0)
     sd = {}
     for fn in sorted(os.listdir(path)):
         if fn.endswith(".safetensors"):
@@ -525,6 +532,7 @@ class ReadEngine:
         self.finished = torch.zeros(R, **i32)
         self.rope_delta = torch.zeros(R, **i32)
         self.out_tokens = None
+        self._seen = None
         self._tok_bufs = {}
         self._ws_dec = None
         self._ws_rows = 0
@@ -650,7 +658,8 @@ class ReadEngine:
 
     # ------------------------------------------------------------------------------------------ generate
     def generate(self, pages: list[np.ndarray], prompts: list[np.ndarray], max_new: int, min_new: int = 0,
-                 forced: np.ndarray | None = None, return_logits: bool = False, use_graph: bool = True):
+                 forced: np.ndarray | None = None, return_logits: bool = False, use_graph: bool = True,
+                 repetition_penalty: float | None = None):
         """Greedy reads.  pages[i]: uint8 [H, W, 3] at tower resolution; prompts[i]: int32 token ids containing one run
         of image placeholders sized for pages[i].  Returns list of generated-token lists (and, for tests, the per-step
         logits of every read when return_logits; `forced` [R][max_new] teacher-forces the fed tokens)."""
@@ -708,10 +717,22 @@ class ReadEngine:
         self.out_tokens = self._tok_bufs[max_new]
         self.out_tokens.fill_(c.pad_id)
         eos = (C.c_int * 4)(*(list(c.eos_ids) + [0] * 4)[:4])
+        # repetition penalty (HF RepetitionPenaltyLogitsProcessor): a bitmap of the ids in prompt + output per read
+        rp = float(c.repetition_penalty if repetition_penalty is None else repetition_penalty)
+        seen_ld = (c.vocab + 31) // 32
+        if rp != 1.0:
+            if self._seen is None:
+                self._seen = torch.zeros(self.max_reads, seen_ld, dtype=torch.int32, device=dev)  # stable address (graphs)
+            bits = np.zeros((R, seen_ld * 32), np.uint8)
+            for r in range(R):
+                bits[r, np.asarray(prompts[r], np.int64)] = 1
+            words = np.packbits(bits, axis=1, bitorder="little").view(np.uint32).astype(np.int64).astype(np.int32, casting="unsafe")
+            self._seen[:R].copy_(torch.from_numpy(words.reshape(R, seen_ld)).to(dev))
         gs = _lib.GenState(cur_ids=_lib.ptr(self.cur_ids), lens=_lib.ptr(self.lens), n_gen=_lib.ptr(self.n_gen),
                            finished=_lib.ptr(self.finished), out_tokens=_lib.ptr(self.out_tokens),
                            rope_delta=_lib.ptr(self.rope_delta), max_new=max_new, min_new=min_new,
-                           n_eos=min(len(c.eos_ids), 4), pad_id=c.pad_id, eos=eos)
+                           n_eos=min(len(c.eos_ids), 4), pad_id=c.pad_id, eos=eos,
+                           seen=_lib.ptr(self._seen) if rp != 1.0 else None, seen_ld=seen_ld, rep_penalty=rp)
         pb = min(self.prefill_batch, R)
         ws = self._dec_ws(max(pb * Tp, self.max_reads))
         step_logits = [] if return_logits else None
@@ -730,12 +751,15 @@ class ReadEngine:
         mark("prefill")
         if return_logits:
             step_logits.append(torch.cat(first_logits, dim=0))
+        def feed(col):  # teacher forcing: the fed token replaces the chosen one (the select kernel adds what it was fed
+            self.cur_ids[:R].copy_(torch.from_numpy(np.ascontiguousarray(forced[:, col]).astype(np.int32)).to(dev))  # to the bitmap)
+
         if forced is not None:
-            self.cur_ids[:R].copy_(torch.from_numpy(np.ascontiguousarray(forced[:, 0]).astype(np.int32)).to(dev))
+            feed(0)
         splits = self.attn_splits or (1 if R * c.kv_heads >= 160 else max(2, min(16, 768 // max(1, R * c.kv_heads))))
         steps = max_new - 1
         if use_graph and not return_logits and forced is None and steps > 0:
-            key = (R, splits, max_new, min_new)
+            key = (R, splits, max_new, min_new, rp)
             if key not in self._graphs:
                 # one eager step first: lazy one-time kernel attributes must not be set inside a capture
                 _lib.check(lib.hwocr_decode_step(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs), R, splits, st))
@@ -759,7 +783,7 @@ class ReadEngine:
                 if return_logits:
                     step_logits.append(self._bufs["logits"][:R].clone())
                 if forced is not None and i + 1 < max_new:
-                    self.cur_ids[:R].copy_(torch.from_numpy(np.ascontiguousarray(forced[:, i + 1]).astype(np.int32)).to(dev))
+                    feed(i + 1)
         mark("decode")
         torch.cuda.current_stream().synchronize()
         if marks:

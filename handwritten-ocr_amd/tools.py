@@ -91,7 +91,8 @@ def run_ocr_batch(images: list, params: dict | None = None) -> list[str]:
             page, ids = processor.prepare(img, prompt)
             pages.append(page)
             prompts.append(ids)
-        for toks in model.generate(pages, prompts, max_new=max_new, min_new=min_new):
+        for toks in model.generate(pages, prompts, max_new=max_new, min_new=min_new,
+                                   repetition_penalty=params.get("repetition_penalty")):  # None: the checkpoint's default
             texts.append(processor.decode(toks, skip_special_tokens=True))
     return texts
 

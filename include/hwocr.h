@@ -114,9 +114,13 @@ int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_stride, con
 int hwocr_embed_splice(const int* ids, const int* img_row, const void* table, const void* img, void* out, int rows,
                        int D, float scale, hwocr_stream_t stream);
 
+/* seen (optional): bitmap [nseq][seen_ld 32-bit words] of the token ids already in a read's prompt + output; with
+ * rep_penalty != 1 their fp32 scores are divided (positive) or multiplied (negative) by it before the argmax — HF
+ * RepetitionPenaltyLogitsProcessor, which the Qwen2.5-VL / olmOCR generation configs switch on.  The caller fills in the
+ * prompt's ids; every later call first adds the id it was fed (cur_ids on entry, when n_gen > 0) */
 int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_ids, int* lens, int* n_gen,
                          int* finished, int* out_tokens, int max_new, int min_new, const int* eos, int n_eos,
-                         int pad_id, hwocr_stream_t stream);
+                         int pad_id, unsigned* seen, int seen_ld, float rep_penalty, hwocr_stream_t stream);
 
 /* ---- model-level entry points (what run_ocr's model.generate expands to) ----------------------------------- */
 
@@ -197,6 +201,9 @@ typedef struct {
   int *cur_ids, *lens, *n_gen, *finished, *out_tokens, *rope_delta; /* device int32 */
   int max_new, min_new, n_eos, pad_id;
   int eos[4];
+  unsigned* seen; /* repetition-penalty bitmap [reads][seen_ld] (see hwocr_argmax_advance) or NULL */
+  int seen_ld;
+  float rep_penalty;
 } hwocr_gen_state;
 
 /* prefill nseq reads laid out [nseq][rows_per_seq]; writes KV for reads seq0.. and the first generated token */

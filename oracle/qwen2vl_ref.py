@@ -361,22 +361,32 @@ class Qwen2VLRef:
         pos3 = torch.full((3, 1), past + delta, dtype=torch.long)
         return self.lm_head(self.decoder(emb, pos3, cache))[0]
 
-    def generate(self, input_ids, pixel_values, grids, max_new: int, min_new: int = 0, forced: list | None = None):
+    def generate(self, input_ids, pixel_values, grids, max_new: int, min_new: int = 0, forced: list | None = None,
+                 repetition_penalty: float = 1.0):
         """Greedy loop (HF generation/utils.py:2783-2973 with do_sample=False): argmax of the fp32 copy of the last
         logits, EOS suppressed below min_new, stop at EOS / max_new.  `forced` teacher-forces the fed tokens while
-        still recording every step's logits.  Returns (tokens, per-step logits [n, V])."""
+        still recording every step's logits.  `repetition_penalty`: HF generation/logits_process.py
+        RepetitionPenaltyLogitsProcessor over prompt + fed tokens.  Returns (tokens, per-step logits [n, V])."""
         c = self.c
         logits, cache, delta = self.prefill(input_ids, pixel_values, grids)
         last = logits[-1]
         toks, steps = [], []
+        seen = set(int(t) for t in input_ids.tolist())
+        self.processed_scores = []  # fp32 scores after the logits processors: what HF returns as `scores`
         for n in range(max_new):
             lf = last.float().clone()
             steps.append(last)
+            if repetition_penalty != 1.0:
+                idx = torch.tensor(sorted(seen))
+                sc = lf[idx]
+                lf[idx] = torch.where(sc < 0, sc * repetition_penalty, sc / repetition_penalty)
             if n < min_new:
                 lf[list(c.eos_ids)] = -float("inf")
+            self.processed_scores.append(lf)
             t = int(torch.argmax(lf))
             toks.append(t)
             fed = forced[n] if forced is not None else t
+            seen.add(int(fed))
             if forced is None and t in c.eos_ids:
                 break
             if n + 1 < max_new:

@@ -137,6 +137,48 @@ def test_eos_stops_a_read(eng):
     assert out == free[: first + 1]
 
 
+def test_repetition_penalty_matches_hf(eng):
+    """Greedy with the repetition penalty of the Qwen2.5-VL / olmOCR generation defaults, teacher-forced on HF's stream:
+    the engine's choices agree wherever HF's processed scores are decisive; graph replay == eager when free-running."""
+    g = tiny_case("bf16")
+    meta = tiny_meta()["cases"]
+    cases = ["a", "b"]
+    pages = [_page(eng, g, c) for c in cases]
+    prompts = [g[f"{c}.input_ids"].numpy() for c in cases]
+    pen = meta["a"]["repetition_penalty"]
+    forced = np.stack([g[f"{c}.rp_tokens"].numpy() for c in cases])
+    n = forced.shape[1]
+    toks, logits = eng.generate(pages, prompts, max_new=n, min_new=n, forced=forced, return_logits=True, repetition_penalty=pen)
+    for r, c in enumerate(cases):
+        want = g[f"{c}.rp_scores"]
+        # the engine returns raw logits: apply HF's rule on the host (ids of prompt + fed tokens, EOS suppressed) ...
+        got = logits[r].float().cpu().clone()
+        seen = set(prompts[r].tolist())
+        for k in range(n):
+            idx = torch.tensor(sorted(seen))
+            sc = got[k, idx]
+            got[k, idx] = torch.where(sc < 0, sc * pen, sc / pen)
+            got[k, list(eng.cfg.eos_ids)] = -float("inf")
+            seen.add(int(forced[r, k]))
+        finite = torch.isfinite(want)
+        assert torch.equal(torch.isfinite(got), finite)
+        scale = max(1.0, float(want[finite].abs().max()))
+        d = (got[finite] - want[finite]).abs()
+        assert float(d.mean()) <= 5e-3 * scale and float(d.max()) <= 6e-2 * pen * scale, (float(d.mean()), float(d.max()))
+        # ... and the kernel's own choice must be the argmax of exactly those processed scores: it agrees with HF wherever
+        # HF's margin exceeds twice the largest score difference
+        top2 = want.topk(2, -1).values
+        decisive = (top2[:, 0] - top2[:, 1]) > 2 * float(d.max())
+        assert int(decisive.sum()) >= n // 3
+        agree = torch.tensor([a == b for a, b in zip(toks[r], forced[r].tolist())])
+        assert bool(agree[decisive].all()), (toks[r], forced[r].tolist())
+        assert toks[r] == got.argmax(-1).tolist(), "the select kernel must pick the argmax of the penalised scores"
+    plain = eng.generate(pages, prompts, max_new=n, min_new=n)
+    eager = eng.generate(pages, prompts, max_new=n, min_new=n, use_graph=False, repetition_penalty=pen)
+    graph = eng.generate(pages, prompts, max_new=n, min_new=n, use_graph=True, repetition_penalty=pen)
+    assert eager == graph and eager != plain
+
+
 def test_eos_in_graph_mode_and_mixed_lengths(eng):
     """Graph-replayed decode with reads that stop at different steps: a finished read pads on in lockstep and its output
     ends at its EOS; the loop leaves early once every read has stopped."""

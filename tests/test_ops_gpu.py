@@ -531,7 +531,7 @@ def test_argmax_advance_semantics():
     outt = torch.full((B, max_new), -1, dtype=torch.int32, device=DEV)
     eos = (C.c_int * 4)(999, 0, 0, 0)
     rc = lib().hwocr_argmax_advance(p(logits), V, V, B, p(cur), p(lens), p(n_gen), p(fin), p(outt), max_new, 2, eos, 1,
-                                    123, st())
+                                    123, None, 0, 1.0, st())
     assert rc == 0
     sync()
     assert cur.tolist() == [10, 5, 999, 123]
@@ -539,3 +539,39 @@ def test_argmax_advance_semantics():
     assert n_gen.tolist() == [1, 1, 4, 4]
     assert fin.tolist() == [0, 0, 1, 1]
     assert outt[0, 0] == 10 and outt[1, 0] == 5 and outt[2, 3] == 999 and outt[3, 3] == 123
+
+
+def test_argmax_repetition_penalty():
+    """HF RepetitionPenaltyLogitsProcessor inside the select kernel: ids in the bitmap have their fp32 score divided
+    (positive) or multiplied (negative) by the penalty; the token a step was fed joins the bitmap first (not after a
+    prefill, n_gen == 0; not for a finished read)."""
+    import ctypes as C
+    V, B, max_new, pen = 1024, 4, 4, 1.5
+    logits = torch.full((B, V), -3.0, dtype=torch.bfloat16, device=DEV)
+    logits[0, 40], logits[0, 41] = 6.0, 5.0      # 40 is in the bitmap: 6 / 1.5 = 4 < 5 -> 41 wins
+    logits[1, :] = -8.0
+    logits[1, 7], logits[1, 900] = -2.0, -2.5    # 7 is the token this step was fed: -2 * 1.5 = -3 < -2.5 -> 900 wins
+    logits[2, 77] = 9.0                          # finished read: pad, bitmap untouched
+    logits[3, 12], logits[3, 13] = 6.0, 5.0      # n_gen == 0 (first pick after a prefill): the stale cur_id 12 is NOT added
+    seen = torch.zeros(B, V // 32, dtype=torch.int32, device=DEV)
+    seen[0, 40 // 32] = 1 << (40 % 32)
+    cur = torch.tensor([3, 7, 77, 12], dtype=torch.int32, device=DEV)
+    lens = torch.tensor([3, 3, 3, 3], dtype=torch.int32, device=DEV)
+    n_gen = torch.tensor([2, 1, 1, 0], dtype=torch.int32, device=DEV)
+    fin = torch.tensor([0, 0, 1, 0], dtype=torch.int32, device=DEV)
+    outt = torch.full((B, max_new), -1, dtype=torch.int32, device=DEV)
+    eos = (C.c_int * 4)(1023, 0, 0, 0)
+    assert lib().hwocr_argmax_advance(p(logits), V, V, B, p(cur), p(lens), p(n_gen), p(fin), p(outt), max_new, 0, eos, 1, 5,
+                                      p(seen), V // 32, pen, st()) == 0
+    sync()
+    assert cur.tolist() == [41, 900, 5, 12]
+    s = seen.cpu()
+    assert int(s[0, 0]) == 1 << 3 and int(s[0, 1]) == 1 << 8      # fed token 3 added; the new pick 41 is not (yet)
+    assert int(s[1, 0]) == 1 << 7 and int(s[1].abs().sum()) == 1 << 7
+    assert int(s[2].abs().sum()) == 0 and int(s[3].abs().sum()) == 0
+    # penalty 1: nothing is rescaled
+    cur.copy_(torch.tensor([3, 7, 77, 12], dtype=torch.int32))
+    assert lib().hwocr_argmax_advance(p(logits), V, V, B, p(cur), p(lens), p(n_gen), p(fin), p(outt), max_new, 0, eos, 1, 5,
+                                      p(seen), V // 32, 1.0, st()) == 0
+    sync()
+    assert cur.tolist()[:2] == [40, 7]

@@ -82,3 +82,28 @@ def test_window_index_partition(gh, gw):
     assert sorted(order.tolist()) == list(range(n)) and sum(lens) == gh * gw
     if (gh, gw) == (72, 72):
         assert lens == [64] * 81
+
+
+@pytest.mark.parametrize("family", FAMILIES)
+@pytest.mark.parametrize("tag,dtype", [("fp32", torch.float32), ("bf16", torch.bfloat16)])
+def test_oracle_repetition_penalty_matches_hf(tag, dtype, family):
+    """Greedy with `repetition_penalty` (the deterministic part of the Qwen2.5-VL / olmOCR generation defaults): the token
+    stream and the processed scores HF returns, teacher-forced on HF's own stream."""
+    for case in ("a", "b"):
+        meta = tiny_meta(family)["cases"][case]
+        g = tiny_case(tag, family)
+        ref = Qwen2VLRef(tiny_ref_config(family), tiny_weights(dtype, family))
+        hf = g[f"{case}.rp_tokens"].tolist()
+        toks, _ = ref.generate(g[f"{case}.input_ids"].long(), g[f"{case}.pixel_values"], [tuple(meta["grid_thw"])],
+                               max_new=len(hf), min_new=len(hf), forced=hf, repetition_penalty=meta["repetition_penalty"])
+        got, want = torch.stack(ref.processed_scores), g[f"{case}.rp_scores"]
+        finite = torch.isfinite(want)
+        assert torch.equal(torch.isfinite(got), finite)
+        tol = 1e-4 if dtype == torch.float32 else 1e-2
+        assert torch.allclose(got[finite], want[finite], rtol=tol, atol=tol * max(1.0, float(want[finite].abs().max())))
+        top2 = want.topk(2, -1).values
+        decisive = (top2[:, 0] - top2[:, 1]) > (1e-5 if dtype == torch.float32 else 0.05)
+        agree = torch.tensor([a == b for a, b in zip(toks, hf)])
+        assert bool(agree[decisive].all())
+        if (family, case) == ("qwen2_vl", "a"):  # 10 of its 24 tokens differ from the plain greedy stream
+            assert toks != g[f"{case}.greedy_tokens"].tolist(), "the penalty must change this stream"

@@ -300,6 +300,8 @@ def make_image() -> None:
 
 
 # ------------------------------------------------------------------------------------------------ model
+REP_PENALTY = 1.3  # strong enough to change several greedy choices of the tiny models
+
 TINY = dict(
     vision=dict(depth=2, embed_dim=64, hidden_size=256, hidden_act="quick_gelu", mlp_ratio=2, num_heads=2, in_channels=3,
                 patch_size=14, spatial_merge_size=2, temporal_patch_size=2),
@@ -420,6 +422,14 @@ def make_model(family: str = "qwen2_vl") -> None:
                                      attention_mask=torch.ones_like(input_ids), do_sample=False, max_new_tokens=N_NEW,
                                      min_new_tokens=N_NEW, output_logits=True, return_dict_in_generate=True)
             new = gen.sequences[0, input_ids.shape[1]:]
+            # the deterministic part of the Qwen2.5-VL / olmOCR generation defaults: greedy with a repetition penalty
+            with torch.no_grad():
+                gen_rp = model.generate(input_ids=input_ids, pixel_values=pv, image_grid_thw=grid, mm_token_type_ids=mm,
+                                        attention_mask=torch.ones_like(input_ids), do_sample=False, max_new_tokens=N_NEW,
+                                        min_new_tokens=N_NEW, repetition_penalty=REP_PENALTY, output_scores=True,
+                                        return_dict_in_generate=True)
+            tensors[f"{cname}.rp_tokens"] = gen_rp.sequences[0, input_ids.shape[1]:].to(torch.int32)
+            tensors[f"{cname}.rp_scores"] = torch.stack([sc[0] for sc in gen_rp.scores]).float().contiguous()
             tensors[f"{cname}.page"] = torch.from_numpy(page.copy())
             tensors[f"{cname}.pixel_values"] = pv.contiguous()
             tensors[f"{cname}.input_ids"] = input_ids[0].to(torch.int32)
@@ -430,6 +440,7 @@ def make_model(family: str = "qwen2_vl") -> None:
             for k, v in acts.items():
                 tensors[f"{cname}.{k}"] = (v[0] if v.dim() == 3 else v).contiguous()
             meta["cases"][cname] = {"page_seed": seed, "page_hw": [h, w], "grid_thw": grid[0].tolist(), "n_new": N_NEW,
+                                    "repetition_penalty": REP_PENALTY,
                                     "rope_delta": int(delta[0]), "T": len(ids)}
         save_file(tensors, os.path.join(GOLD, f"{stem}_{tag}.safetensors"))
         print(f"{stem}_{tag}.safetensors:", {k: tuple(v.shape) for k, v in tensors.items() if k.startswith("a.")})
