@@ -44,7 +44,7 @@ inline int pick_splitk_stream(int K, int N) {
 }
 }  // namespace
 
-extern "C" int hwocr_abi_version(void) { return 3; }
+extern "C" int hwocr_abi_version(void) { return 4; }
 
 static char g_last_error[256] = "";
 extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text) {
