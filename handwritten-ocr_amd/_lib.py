@@ -24,6 +24,14 @@ _CODES = {1: "HWOCR_EINVAL (argument rejected by the launcher)", 2: "HWOCR_ELAUN
 
 
 def check(rc: int, what: str = "") -> None:
+    if os.environ.get("HWOCR_DEBUG_SYNC"):  # diagnosis: surface an asynchronous device fault at the call that caused it
+        import sys
+
+        import torch
+
+        sys.stderr.write(f"[hwocr] {what or 'call'} rc={rc}\n")
+        sys.stderr.flush()
+        torch.cuda.synchronize()
     if rc != 0:
         detail = ""
         if rc == 2 and _hip is not None:

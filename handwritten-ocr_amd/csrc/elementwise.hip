@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void decode_qkv_finish_kernel(DecQkvArgs a) {
   }
   __syncthreads();
   const int slot = a.lens[b] - 1;
-  const int p = slot + a.rope_delta[b];  // all position axes coincide on generated tokens
+  const int p = max(0, slot + a.rope_delta[b]);  // all position axes coincide on generated tokens (never before the table)
   // q and k heads: pairs (d, d + DHD/2)
   for (int id = tid; id < (a.Hq + a.Hkv) * HALF; id += 256) {
     const int hy = id / HALF, i = id % HALF;

@@ -803,3 +803,141 @@ class ReadEngine:
         if return_logits:
             return out, torch.stack(step_logits, dim=1)  # [R][steps][V]
         return out
+
+    # ------------------------------------------------------------------------------------------ continuous batching
+    def generate_stream(self, pages: list, prompts: list, max_new: int, min_new: int = 0, sync_every: int = 16,
+                        repetition_penalty: float | None = None, min_admit: int = 0) -> list[list[int]]:
+        """Greedy reads of ANY number of (page, prompt) pairs through the engine's `max_reads` decode slots, refilled as
+        reads finish (EOS or max_new): the lockstep `generate` keeps a whole batch decoding until its longest read is done,
+        which with the reference's 2048-token budget (config.py:19) and pages of a few hundred tokens idles most slots.
+        Every `sync_every` decode steps the host looks at the stop flags, harvests finished reads, and prefills new ones
+        into the freed slots (vision + prefill run while the other slots wait; their KV stays in place) — once at least
+        `min_admit` slots are free (default an eighth of the slots: the tower and the prefill GEMMs want rows), or nothing
+        is decoding.  Results are in input order and equal `generate` on each read alone (reads never see each other)."""
+        c, lib, dev = self.cfg, self.lib, self.dev
+        N = len(pages)
+        if N == 0:
+            return []
+        R = min(self.max_reads, N)
+        st = _lib.stream_handle()
+        Tmax = max(len(p) for p in prompts)
+        if _ceil(Tmax, 64) + max_new + sync_every > self.ctx:
+            raise ValueError(f"prompt ({Tmax}) + max_new ({max_new}) + sync_every ({sync_every}) exceeds the KV cache length {self.ctx}")
+        if max_new not in self._tok_bufs:
+            self._tok_bufs[max_new] = torch.empty((self.max_reads, max_new), dtype=torch.int32, device=dev)
+        self.out_tokens = self._tok_bufs[max_new]
+        eos = (C.c_int * 4)(*(list(c.eos_ids) + [0] * 4)[:4])
+        rp = float(c.repetition_penalty if repetition_penalty is None else repetition_penalty)
+        seen_ld = (c.vocab + 31) // 32
+        if rp != 1.0 and self._seen is None:
+            self._seen = torch.zeros(self.max_reads, seen_ld, dtype=torch.int32, device=dev)
+        gs = _lib.GenState(cur_ids=_lib.ptr(self.cur_ids), lens=_lib.ptr(self.lens), n_gen=_lib.ptr(self.n_gen),
+                           finished=_lib.ptr(self.finished), out_tokens=_lib.ptr(self.out_tokens),
+                           rope_delta=_lib.ptr(self.rope_delta), max_new=max_new, min_new=min_new,
+                           n_eos=min(len(c.eos_ids), 4), pad_id=c.pad_id, eos=eos,
+                           seen=_lib.ptr(self._seen) if rp != 1.0 else None, seen_ld=seen_ld, rep_penalty=rp)
+        # idle slots decode a finished one-token read (cheap) until a real read moves in
+        self.finished[:R].fill_(1)
+        self.lens[:R].fill_(1)
+        self.rope_delta[:R].zero_()   # a parked slot's position is lens - 1 + delta: a stale negative delta would index before the rope table
+        self.n_gen[:R].zero_()
+        self.cur_ids[:R].fill_(c.pad_id)
+        slot_read = [-1] * R
+        results: list = [None] * N
+        nxt = 0
+        splits = self.attn_splits or (1 if R * c.kv_heads >= 160 else max(2, min(16, 768 // max(1, R * c.kv_heads))))
+        ws = self._dec_ws(max(min(self.prefill_batch, R) * _ceil(Tmax, 64), self.max_reads))
+
+        def admit(slots: list[int]) -> None:
+            nonlocal nxt
+            reads = list(range(nxt, nxt + len(slots)))
+            nxt += len(slots)
+            emb, grids, tok_rows = self.encode_pages([pages[r] for r in reads])
+            T = [len(prompts[r]) for r in reads]
+            Tp = _ceil(max(T), 64)
+            n = len(reads)
+            ids = np.zeros((n, Tp), np.int32)
+            img_row = np.full((n, Tp), -1, np.int32)
+            pos3 = np.zeros((3, n, Tp), np.int32)
+            delta = np.zeros(n, np.int32)
+            for j, r in enumerate(reads):
+                p = np.asarray(prompts[r], np.int32)
+                ids[j, : T[j]] = p
+                m = np.nonzero(p == c.image_token_id)[0]
+                if len(m) != len(tok_rows[j]):
+                    raise ValueError(f"read {r}: {len(m)} image placeholders but the page yields {len(tok_rows[j])} image tokens")
+                img_row[j, m] = tok_rows[j]
+                if c.family == "paligemma":
+                    pos3[:, j, : T[j]], delta[j] = np.arange(1, T[j] + 1, dtype=np.int32), 1
+                else:
+                    pos3[:, j, : T[j]], delta[j] = imageproc.mrope_positions(p, c.image_token_id, [grids[j]], c.merge)
+            d_ids, d_img = torch.from_numpy(ids).to(dev), torch.from_numpy(img_row).to(dev)
+            d_pos, d_seq = torch.from_numpy(pos3).to(dev), torch.tensor(T, dtype=torch.int32, device=dev)
+            sl = torch.tensor(slots, dtype=torch.long, device=dev)
+            self.lens[sl] = d_seq
+            self.rope_delta[sl] = torch.from_numpy(delta).to(dev)
+            self.n_gen[sl] = 0
+            self.finished[sl] = 0
+            self.out_tokens[sl] = c.pad_id
+            if rp != 1.0:
+                bits = np.zeros((n, seen_ld * 32), np.uint8)
+                for j, r in enumerate(reads):
+                    bits[j, np.asarray(prompts[r], np.int64)] = 1
+                words = np.packbits(bits, axis=1, bitorder="little").view(np.uint32).astype(np.int64).astype(np.int32, casting="unsafe")
+                self._seen[sl] = torch.from_numpy(words.reshape(n, seen_ld)).to(dev)
+            # prefill writes consecutive cache slots: one call per run of adjacent slots (slots are sorted)
+            j0 = 0
+            while j0 < n:
+                j1 = j0 + 1
+                while j1 < n and slots[j1] == slots[j1 - 1] + 1 and j1 - j0 < self.prefill_batch:
+                    j1 += 1
+                k = j1 - j0
+                last = torch.tensor([i * Tp + T[j0 + i] - 1 for i in range(k)], dtype=torch.int32, device=dev)
+                pos_chunk = d_pos[:, j0:j1].contiguous()
+                _lib.check(lib.hwocr_prefill(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs),
+                                             _lib.ptr(d_ids[j0:j1]), _lib.ptr(d_img[j0:j1]), _lib.ptr(emb), _lib.ptr(pos_chunk),
+                                             _lib.ptr(d_seq[j0:j1]), _lib.ptr(last), k, Tp, slots[j0], max(T[j0:j1]), st),
+                           "hwocr_prefill")
+                torch.cuda.current_stream().synchronize()
+                j0 = j1
+            for s, r in zip(slots, reads):
+                slot_read[s] = r
+
+        key = (R, splits, max_new, min_new, rp)
+        while True:
+            free = [s for s in range(R) if slot_read[s] < 0]
+            if free and nxt < N and (len(free) >= (min_admit or max(1, R // 8)) or len(free) == R or N - nxt <= len(free)):
+                admit(free[: N - nxt])
+            if all(r < 0 for r in slot_read):
+                break
+            if key not in self._graphs:
+                _lib.check(lib.hwocr_decode_step(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs), R, splits, st))
+                torch.cuda.current_stream().synchronize()
+                g = C.c_void_p()
+                self._gs_keep = (gs, eos)
+                _lib.check(lib.hwocr_decode_graph_create(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs), R, splits,
+                                                         C.byref(g)), "hwocr_decode_graph_create")
+                self._graphs[key] = g
+                _lib.check(lib.hwocr_decode_graph_launch(g, sync_every - 1, st), "hwocr_decode_graph_launch")
+            else:
+                _lib.check(lib.hwocr_decode_graph_launch(self._graphs[key], sync_every, st), "hwocr_decode_graph_launch")
+            torch.cuda.current_stream().synchronize()
+            fin = self.finished[:R].cpu().numpy()
+            ng = self.n_gen[:R].cpu().numpy()
+            done = [s for s in range(R) if slot_read[s] >= 0 and (fin[s] or ng[s] >= max_new)]
+            if done:
+                toks = self.out_tokens[:R].cpu().numpy()
+                for s in done:
+                    seq = toks[s, : min(int(ng[s]), max_new)].tolist()
+                    for k, t in enumerate(seq):
+                        if t in c.eos_ids and k + 1 >= min_new:
+                            seq = seq[: k + 1]
+                            break
+                    results[slot_read[s]] = seq
+                    slot_read[s] = -1
+            idle = torch.tensor([s for s in range(R) if slot_read[s] < 0], dtype=torch.long, device=dev)
+            if len(idle):  # parked: finished one-token reads at position 0 (their context must not grow with the padding steps)
+                self.finished[idle] = 1
+                self.lens[idle] = 1
+                self.rope_delta[idle] = 0
+        return results

@@ -83,17 +83,16 @@ def run_ocr_batch(images: list, params: dict | None = None) -> list[str]:
     prompt = params.get("prompt", config.OCR_PROMPT)
     max_new = params.get("max_new_tokens", config.OCR_MAX_NEW_TOKENS)
     min_new = params.get("min_new_tokens", 0)
-    texts: list[str] = []
-    for s in range(0, len(images), model.max_reads):
-        pages, prompts = [], []
-        for im in images[s: s + model.max_reads]:
-            img = im if isinstance(im, Image.Image) else Image.open(im)
-            page, ids = processor.prepare(img, prompt)
-            pages.append(page)
-            prompts.append(ids)
-        for toks in model.generate(pages, prompts, max_new=max_new, min_new=min_new,
-                                   repetition_penalty=params.get("repetition_penalty")):  # None: the checkpoint's default
-            texts.append(processor.decode(toks, skip_special_tokens=True))
+    pages, prompts = [], []
+    for im in images:
+        img = im if isinstance(im, Image.Image) else Image.open(im)
+        page, ids = processor.prepare(img, prompt)
+        pages.append(page)
+        prompts.append(ids)
+    # continuous batching: reads stop at different lengths (EOS), freed decode slots take the next read
+    streams = model.generate_stream(pages, prompts, max_new=max_new, min_new=min_new,
+                                    repetition_penalty=params.get("repetition_penalty"))  # None: the checkpoint's default
+    texts = [processor.decode(toks, skip_special_tokens=True) for toks in streams]
     return texts
 
 

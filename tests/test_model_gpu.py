@@ -202,6 +202,40 @@ def test_eos_in_graph_mode_and_mixed_lengths(eng):
     assert out[1] == want1
 
 
+def test_continuous_batching_equals_single_reads(eng):
+    """`generate_stream`: seven reads of different lengths through three decode slots, refilled as reads hit EOS — every
+    read's tokens equal what the read produces alone."""
+    from handwritten_ocr_amd import engine
+
+    g = tiny_case("bf16")
+    small = engine.ReadEngine(eng.cfg, tiny_weights(torch.bfloat16), max_reads=3, ctx=256, vit_batch=2, prefill_batch=2)
+    try:
+        pages, prompts = [], []
+        for i in range(7):
+            c = "ab"[i % 2]
+            pages.append(_page(eng, g, c))
+            prompts.append(np.concatenate([g[f"{c}.input_ids"].numpy(), np.asarray([3 + 7 * i, 11 + i], np.int32)]))  # distinct tails
+        n = 40
+        free = [small.generate([p], [q], max_new=n, min_new=n)[0] for p, q in zip(pages, prompts)]
+        # an EOS id that ends the reads at different steps (some never)
+        from collections import Counter
+        eos = Counter(t for seq in free for t in set(seq[2:])).most_common(1)[0][0]
+        old = small.cfg.eos_ids
+        small.cfg.eos_ids = (eos,)
+        try:
+            want = [small.generate([p], [q], max_new=n, min_new=0)[0] for p, q in zip(pages, prompts)]
+            got = small.generate_stream(pages, prompts, max_new=n, min_new=0, sync_every=4)
+            got_rp = small.generate_stream(pages, prompts, max_new=n, min_new=0, sync_every=5, repetition_penalty=1.3)
+            want_rp = [small.generate([p], [q], max_new=n, min_new=0, repetition_penalty=1.3)[0] for p, q in zip(pages, prompts)]
+        finally:
+            small.cfg.eos_ids = old
+        assert got == want
+        assert got_rp == want_rp
+        assert len({len(x) for x in want}) >= 3, "the reads should stop at different steps for this test to mean something"
+    finally:
+        small.close()
+
+
 def test_drop_in_tools_surface(tmp_path, monkeypatch, capsys):
     """run_ocr / run_ocr_batch / unload_ocr_model with the reference's signatures and prints, through the compat node."""
     from handwritten_ocr_amd import tools
