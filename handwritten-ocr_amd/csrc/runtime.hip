@@ -33,11 +33,12 @@ inline int pick_splitk(int K, int N, int want_wgs) {
 }
 // gemm_stream (<= 128 reads, tiled weights) fills the chip by itself; K is split to cut the activation re-staging
 // (x bytes into the CUs = 64 KiB x K / splitk against 1 KiB x N x splitk of slab): measured best 8 slabs, 12 for the
-// long-K / narrow-N down projection (tools/bench_decode_gemm.py sweep), never fewer than 2 K tiles per slice
+// long-K / narrow-N down projection, and slices of at least 6 K tiles (K = 1536: 4 slabs; GEMM + the slab-summing consumer,
+// tools/bench_decode_gemm.py sweep at 126 and 252 reads)
 inline int pick_splitk_stream(int K, int N) {
   const int ktiles = K / 64;
   int s = K >= 4 * N ? 12 : 8;
-  if (s > ktiles / 2) s = ktiles / 2;
+  if (s > ktiles / 6) s = ktiles / 6;
   if (s < 1) s = 1;
   const int per = (ktiles + s - 1) / s;  // every slice must own at least one K tile
   return (ktiles + per - 1) / per;
