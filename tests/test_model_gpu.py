@@ -275,3 +275,41 @@ def test_drop_in_tools_surface(tmp_path, monkeypatch, capsys):
     monkeypatch.setenv("HWOCR_KEEP_RESIDENT", "0")
     tools.unload_ocr_model()
     assert tools._ocr_model is None
+
+
+def test_batch_folder_cli_end_to_end(tmp_path, monkeypatch, capsys):
+    """`python -m handwritten_ocr_amd.batch <folder>` on the real engine (tiny preset): one batched pass for all pages and
+    strategies, the reference's four files per page, texts equal to per-page `run_ocr` reads merged by the same node code."""
+    import json
+
+    from handwritten_ocr_amd import batch, tools
+    from handwritten_ocr_amd.compat import config
+    from handwritten_ocr_amd.synth import make_page
+
+    monkeypatch.setenv("HWOCR_MODEL", "tiny")
+    monkeypatch.setenv("HWOCR_MAX_READS", "4")   # fewer slots than reads: the continuous-batching path refills them
+    monkeypatch.setenv("HWOCR_CTX", "512")
+    monkeypatch.setattr(tools, "_ocr_model", None)
+    monkeypatch.setattr(tools, "_ocr_processor", None)
+    monkeypatch.setattr(config, "OCR_MIN_PIXELS", 28 * 28)
+    monkeypatch.setattr(config, "OCR_MAX_NEW_TOKENS", 24)
+    folder = tmp_path / "pages"
+    folder.mkdir()
+    for i in range(3):
+        Image.fromarray(make_page(60 + i, 70, 100), "RGB").save(folder / f"p{i}.png")
+    batch.main([str(folder), "--output-dir", str(tmp_path / "out")])
+    capsys.readouterr()
+    for i in range(3):
+        txt = (tmp_path / "out" / f"p{i}_transcription.txt").read_text()
+        ev = json.loads((tmp_path / "out" / f"p{i}_trace.json").read_text())
+        assert [e["action"] for e in ev][:2] == ["preprocess", "ocr"] and ev[-1]["action"] == "merge"
+        assert json.loads((tmp_path / "out" / f"p{i}_eval.json").read_text())["pipeline_status"] == "initial_ocr"
+        # the serial path on the same engine: per-read run_ocr through the same node
+        from handwritten_ocr_amd.compat import nodes
+        from handwritten_ocr_amd.compat.state import new_state
+        state = new_state(str(folder / f"p{i}.png"), config)
+        state.update(nodes.node_initial_ocr(state))
+        capsys.readouterr()
+        assert state["current_best"] == txt
+    monkeypatch.setenv("HWOCR_KEEP_RESIDENT", "0")
+    tools.unload_ocr_model()
