@@ -1,6 +1,7 @@
-// Decode-step GEMM: out[Bsz <= 128][N] = x[Bsz][K] . W[N][K]^T with W streamed from HBM exactly once.
+// Decode-step GEMM: out[Bsz <= 256][N] = x[Bsz][K] . W[N][K]^T with W streamed from HBM exactly once
+// (gemm_stream_kernel: up to 128 rows; gemm_stream256_kernel below: 129..256, the default 252 reads in flight).
 //
-// A decode step multiplies the same 1..128 activation rows (one per read in flight) by every decoder weight.  The
+// A decode step multiplies the same activation rows (one per read in flight) by every decoder weight.  The
 // first decode kernel (gemm_skinny_kernel: weights HBM -> VGPR in two register stages, x chunks by LDS-DMA, 2-4 waves)
 // kept 4-8 KB in flight per wave and measured 1.7-3.1 TB/s of weights at 126 rows.  This kernel:
 //   * W is the fragment-tiled copy ([N/16][K/32][lane][8], hwocr_tile_weights): the K axis of a 16-row tile is ONE
@@ -10,11 +11,12 @@
 //     lines), 16-byte chunks XOR-swizzled on the SOURCE address so that the B fragment reads are conflict-free.
 //   * ring of 3 stages of one 64-wide K tile: while tile t is multiplied, t+1 and t+2 are in flight; one raw s_barrier
 //     per K tile; each wave waits with a COUNTED vmcnt for its own DMAs only.
-//   * one workgroup of 16 waves per CU, wave w = weight tile w of the group x all MT row tiles.  Weight tiles are dealt
-//     to workgroups as balanced contiguous ranges of at most 16 tiles, so grid.x * splitk can be made ~256 (one round)
-//     whatever N is: 37888 rows (Qwen2.5-VL-7B gate/up) = 1184 tile pairs = 4.6 pairs per CU, 92 % balance.
-//     SwiGLU: the gate tile sits in the even wave and the up tile in the odd one; the up accumulators cross through the
-//     idle ring once at the end.
+//   * one workgroup of 16 waves per CU.  Staging: wave w brings in weight tile w of the group and a share of the x rows.
+//     Multiply: 16 x 1 (wave w = tile w x all row tiles) up to 64 rows, 2 row halves x 8 tile pairs at 65..128 rows.
+//     Weight tiles are dealt to workgroups as balanced contiguous ranges of at most 16 tiles, so grid.x * splitk can be
+//     made ~256 (one round) whatever N is: 37888 rows (Qwen2.5-VL-7B gate/up) = 1184 tile pairs = 4.6 pairs per CU, 92 %
+//     balance.  Gated epilogues in the 16 x 1 form: the gate tile sits in the even wave and the up tile in the odd one;
+//     the up accumulators cross through the idle ring once at the end.
 // What bounds it (7B gate/up, 271 MB of weights, 126 rows): every workgroup must also pull the whole activation tile
 // (126 x K x 2 B) through L2 -> LDS, and the bytes entering the CUs top out near 8 TB/s chip-wide = 31-33 GB/s per CU —
 // the same per-CU rate the 256x256 prefill GEMM runs at, and the same whether the bytes come by LDS-DMA or by
@@ -23,7 +25,7 @@
 // A variant with the weights HBM -> VGPR in a 4-deep hand-unrolled register ring (exact compiler vmcnt waits once the
 // loop has no separate prologue and no load under a t-dependent branch) and x by plain loads + ds_write ran at the same
 // bytes-into-CU ceiling but re-read weight tiles for idle waves: 3.3 TB/s; dropped.
-// Epilogues as gemm_skinny: PARTIAL fp32 split-K slabs, LINEAR (+bias), SWIGLU on interleaved gate/up tile pairs.
+// Epilogues as gemm_skinny: PARTIAL fp32 split-K slabs, LINEAR (+bias), SWIGLU / GEGLU on interleaved gate/up tile pairs.
 #include "gemm_common.cuh"
 #include <cstdlib>
 
