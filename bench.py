@@ -36,6 +36,7 @@ import torch  # noqa: E402
 
 WORKLOAD_NAMES = {"paligemma-3b": "PaliGemma-3B (SigLIP-So400m 896 + Gemma-2B, bf16)", "qwen2-vl-2b": "Qwen2-VL-2B", "qwen2.5-vl-7b": "Qwen2.5-VL-7B / olmOCR-2-7B", "qwen2.5-vl-3b": "Qwen2.5-VL-3B"}
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+FP8_MFMA_PEAK_TFLOPS = 5000.0    # MI355X_MICROARCH.md: ~5 PF dense fp8 (block-scaled f8f6f4 MFMA forms)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -300,6 +301,8 @@ def main() -> None:
     ap.add_argument("--vit-batch", type=int, default=12)
     ap.add_argument("--prefill-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true",
+                    help="E4M3 wide GEMMs for the vision tower and the prefill (BASELINE config 4; not the headline configuration)")
     args = ap.parse_args()
 
     from handwritten_ocr_amd import _lib, engine, shard, text, tokenizer
@@ -320,7 +323,7 @@ def main() -> None:
     n_img_tokens = (cfg.image_size // cfg.patch_size) ** 2 if cfg.family == "paligemma" else 1296
     ctx = 2048 if n_img_tokens + 64 + args.new_tokens <= 2048 else (n_img_tokens + 128 + args.new_tokens + 63) // 64 * 64
     eng = engine.ReadEngine(cfg, sd, max_reads=n_reads, ctx=ctx, device=str(dev), vit_batch=args.vit_batch,
-                            prefill_batch=args.prefill_batch)
+                            prefill_batch=args.prefill_batch, fp8=args.fp8)
     del sd
     eng.collect_timings = True
     tok = tokenizer.ByteTokenizer(cfg, fold_unknown=True)
@@ -349,7 +352,7 @@ def main() -> None:
         step()
     phases = []
     barrier()
-    _lib.check(lib.hwocr_profile_enable(1))
+    _lib.check(lib.hwocr_profile_enable(2 if args.fp8 else 1))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -379,6 +382,7 @@ def main() -> None:
     kv_bytes = n_reads * cfg.layers * 2 * cfg.kv_heads * hd * 2 * (T + args.new_tokens / 2)
     # HBM-side traffic of the dominant kernel: not measurable in-process — taken from the committed summary of separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (tools/pmc_summary.py, corrections stated there)
+    mfma_peak = FP8_MFMA_PEAK_TFLOPS if args.fp8 else BF16_MFMA_PEAK_TFLOPS
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -388,15 +392,18 @@ def main() -> None:
     out = {
         "metric": "handwritten pages/sec (1024x1024, 3-strategy reads)", "value": value, "unit": "pages/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp8-e4m3 wide GEMMs (vision tower + prefill), bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"{WORKLOAD_NAMES.get(cfg.name, cfg.name)} shape (random init) x {args.side}x{args.side} synthetic handwritten pages, "
                                f"{args.reads} preprocessing-strategy reads per page, {args.new_tokens} greedy tokens per read",
                    "pages_per_step_per_gpu": args.pages, "reads_in_flight": n_reads, "prompt_tokens": T,
                    "image_tokens": int((prompts[0] == cfg.image_token_id).sum()), "new_tokens": args.new_tokens,
                    "parallelism": f"replicas x{world}, pages sharded, RCCL gather of token streams"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_wide256_kernel (bf16 256x256x64 MFMA GEMM, 8 waves, staggered phases)",
-                     "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+        "roofline": {"bound": "mfma",
+                     "kernel": ("gemm_wide256_kernel<FP8> (E4M3 256x256x128 MFMA GEMM on v_mfma_f32_16x16x128_f8f6f4, 8 waves, staggered phases)"
+                                if args.fp8 else "gemm_wide256_kernel (bf16 256x256x64 MFMA GEMM, 8 waves, staggered phases)"),
+                     "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s",
+                     "frac": achieved / mfma_peak, "traffic": None if args.fp8 else traffic,
                      "traffic_note": "bytes per launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)",
                      "launches": int(n.value), "avg_launch_ms": ms.value / max(1, n.value),
                      "algorithmic_flops_per_launch": fl.value / max(1, n.value),

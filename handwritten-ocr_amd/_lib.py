@@ -39,9 +39,15 @@ def check(rc: int, what: str = "") -> None:
         raise HwocrError(f"{what or 'hwocr call'} failed: {_CODES.get(rc, rc)}{detail}")
 
 
+class W8(C.Structure):
+    """hwocr_w8: E4M3 copy of a weight matrix + one fp32 scale per row (both NULL: the GEMM stays bf16)."""
+    _fields_ = [("w", P), ("scale", P)]
+
+
 class VitBlock(C.Structure):
     _fields_ = [(n, P) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_w", "ln2_b",
-                                  "fc1_w", "fc1_b", "fc2_w", "fc2_b")] + [("windowed", I)]
+                                  "fc1_w", "fc1_b", "fc2_w", "fc2_b")] + [("windowed", I)] + [
+        (n, W8) for n in ("qkv8", "proj8", "fc18", "fc28")]
 
 
 class Vit(C.Structure):
@@ -59,12 +65,13 @@ class VitLayout(C.Structure):
 
 
 class VitWs(C.Structure):
-    _fields_ = [(n, P) for n in ("patches", "x", "xn", "qkv", "q", "k", "vt", "attn", "mlp", "merge_mid")]
+    _fields_ = [(n, P) for n in ("patches", "x", "xn", "qkv", "q", "k", "vt", "attn", "mlp", "merge_mid", "q8", "q8s")]
 
 
 class DecLayer(C.Structure):
     _fields_ = [(n, P) for n in ("in_norm_w", "qkv_w", "qkv_b", "o_w", "post_norm_w", "gate_up_w", "down_w",
-                                  "qkv_wt", "o_wt", "gate_up_wt", "down_wt")]
+                                  "qkv_wt", "o_wt", "gate_up_wt", "down_wt")] + [
+        (n, W8) for n in ("qkv8", "o8", "gate_up8", "down8")]
 
 
 class Decoder(C.Structure):
@@ -79,7 +86,8 @@ class Kv(C.Structure):
 
 
 class DecWs(C.Structure):
-    _fields_ = [(n, P) for n in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "logits")]
+    _fields_ = [(n, P) for n in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "logits", "q8",
+                                  "q8s")]
 
 
 class GenState(C.Structure):
@@ -92,6 +100,8 @@ _HIP_SIGS = {
     "hwocr_abi_version": ([], I),
     "hwocr_last_error": ([], C.c_char_p),
     "hwocr_gemm_wide": ([P, P, P, P, P, I, I, I, I, I, I, I, I, P], I),
+    "hwocr_quant_rows_fp8": ([P, P, P, I, I, I, I, P], I),
+    "hwocr_gemm_wide_fp8": ([P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P], I),
     "hwocr_gemm_skinny": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "hwocr_tile_weights": ([P, P, I, I, I, P], I),
     "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, I, P], I),

@@ -562,6 +562,53 @@ extern "C" int hwocr_patchify(const void* img, const void* lut, void* out, int n
   return hwocr_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// E4M3 row quantisation for the fp8 wide GEMM (gemm256.hip): one wave per row, two passes over the row (the second
+// one is an L2 hit): scale = max|x| / 448, Q = e4m3(x * (448 / max|x|)), round-to-nearest-even (v_cvt_pk_fp8_f32).
+// ------------------------------------------------------------------------------------------------
+struct QuantArgs {
+  const bf16* x; unsigned char* q; float* scale;
+  int rows, K, ldx, ldq;
+};
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(QuantArgs a) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= a.rows) return;
+  const int nch = a.K >> 3;
+  const bf16* src = a.x + (long)row * a.ldx;
+  float amax = 0.f;
+  for (int ch = lane; ch < nch; ch += 64) {
+    const bf16x8 v = *(const bf16x8*)(src + ch * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf2f(v[e])));
+  }
+  amax = wave_max(amax);
+  const float inv = amax > 0.f ? 448.0f / amax : 0.f;
+  if (lane == 0) a.scale[row] = amax > 0.f ? amax / 448.0f : 1.0f;
+  unsigned char* dst = a.q + (long)row * a.ldq;
+  for (int ch = lane; ch < nch; ch += 64) {
+    const bf16x8 v = *(const bf16x8*)(src + ch * 8);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(bf2f(v[e]) * inv, -448.0f), 448.0f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    *(int2*)(dst + ch * 8) = make_int2(lo, hi);
+  }
+}
+
+extern "C" int hwocr_quant_rows_fp8(const void* X, void* Q, float* scale, int rows, int K, int ldx, int ldq,
+                                    hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
+  if (!X || !Q || !scale || rows <= 0 || K <= 0 || K % 8 || ldx % 8 || ldq % 8 || ldx < K || ldq < K) return HWOCR_EINVAL;
+  QuantArgs a{(const bf16*)X, (unsigned char*)Q, scale, rows, K, ldx, ldq};
+  hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}
+
 extern "C" int hwocr_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int D, int ldx,
                                int ldo, float eps, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)

@@ -325,7 +325,7 @@ int launch_skinny(const SkinnyArgs& a, int epi, int splitk, bool tiled, hipStrea
 namespace {
 constexpr int PROF_CAP = 1 << 15;
 struct WideProfile {
-  bool on = false;
+  int on = 0;  // 1: time the bf16 wide launches, 2: the fp8 ones
   int n = 0;
   std::vector<hipEvent_t> ev;      // 2 per launch
   std::vector<double> flops;
@@ -339,7 +339,7 @@ extern "C" int hwocr_profile_enable(int on) {
     for (auto& e : g_prof.ev)
       if (hipEventCreate(&e) != hipSuccess) return HWOCR_ELAUNCH;
   }
-  g_prof.on = on != 0;
+  g_prof.on = on;
   if (on) g_prof.n = 0;
   return HWOCR_OK;
 }
@@ -369,7 +369,7 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
   if (epi == EPI_RESIDUAL && (!res || (ldres % 4))) return HWOCR_EINVAL;
   WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)out,
              M, N, K, ldx, ldw, ldo, ldres, (M + BM - 1) / BM, (N + BN - 1) / BN};
-  const bool prof = g_prof.on && g_prof.n < PROF_CAP;
+  const bool prof = g_prof.on == 1 && g_prof.n < PROF_CAP;
   static const bool use256 = [] { const char* e = getenv("HWOCR_GEMM256"); return !e || atoi(e) != 0; }();
   if (use256 && M >= 1024 && N >= 256 && (ldo % 8) == 0 && (epi != EPI_RESIDUAL || (ldres % 8) == 0)) {
     if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
@@ -410,6 +410,28 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
     ++g_prof.n;
   }
   return hwocr_launch_status();
+}
+
+extern "C" int hwocr_gemm_wide_fp8(const void* X8, const float* xscale, const void* W8, const float* wscale,
+                                   const void* bias, const void* res, void* out, int M, int N, int K, int ldx, int ldw,
+                                   int ldo, int ldres, int epi, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
+  if (!X8 || !W8 || !xscale || !wscale || M <= 0 || N <= 0 || K <= 0 || (K % 128) || (N % 8) || (ldx % 16) || (ldw % 16) ||
+      (ldo % 8))
+    return HWOCR_EINVAL;
+  if ((epi == EPI_SWIGLU || epi == EPI_GEGLU) && (N % 32) != 0) return HWOCR_EINVAL;
+  if (epi == EPI_RESIDUAL && (!res || (ldres % 8))) return HWOCR_EINVAL;
+  WideArgs a{(const bf16*)X8, (const bf16*)W8, (const bf16*)bias, (const bf16*)res, (bf16*)out,
+             M, N, K, ldx, ldw, ldo, ldres, 0, 0, xscale, wscale};
+  const bool prof = g_prof.on == 2 && g_prof.n < PROF_CAP;
+  if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
+  const int rc = hwocr_gemm_wide256_fp8(a, epi, stream);
+  if (prof) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], stream);
+    g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
+    ++g_prof.n;
+  }
+  return rc;
 }
 
 // [N][K] row-major -> fragment-tiled copy for gemm_skinny (layout in the kernel comment).  16-byte granules.

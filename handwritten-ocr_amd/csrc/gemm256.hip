@@ -14,6 +14,12 @@
 //   * Every phase issues ONE unit, 7 units (1.75 K tiles) ahead of the consumer; the unit it overwrites was last read one
 //     phase earlier.  Only ph3 waits, with a COUNTED vmcnt that retires the next K tile and leaves 3 units in flight.
 // The weight tile is the MFMA A operand, so each lane owns 4 consecutive output features (8-byte stores).
+//
+// FP8 variant (BASELINE config 4: E4M3 weights + activations): the SAME byte-level pipeline over rows of 128 fp8 values
+// (a K tile = 128 elements, so half as many K tiles), multiplied with v_mfma_f32_16x16x128_f8f6f4 (the 2x-rate form): a
+// lane's 32-byte operand = the two 16-byte chunks the bf16 form feeds to its two k-steps.  The k order inside the
+// instruction is therefore permuted, identically for both operands, which a dot product does not see.  Operands carry
+// one fp32 scale per row (activation) / per output feature (weight); the epilogue multiplies them in before the bias.
 #include "gemm_common.cuh"
 #include <cstdlib>
 #include <type_traits>
@@ -28,17 +34,34 @@ constexpr int STAGE = 2 * TILE;      // activation tile, then weight tile
 constexpr int LDS_BYTES = 2 * STAGE; // 128 KiB
 constexpr int AHEAD = 7;             // units in flight ahead of the consuming phase
 
-template <int MH, int NH>
-__device__ __forceinline__ void quadrant_mma(f32x4 (&acc)[4][8], const bf16x8 (&wf)[2][2][2], const bf16x8 (&xf)[4][2]) {
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <bool FP8, int MH, int NH>
+__device__ __forceinline__ void quadrant_mma(f32x4 (&acc)[4][8], const i32x4 (&wf)[2][2][2], const i32x4 (&xf)[4][2]) {
   __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
+  if constexpr (FP8) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        const i32x8 wa = __builtin_shufflevector(wf[NH][j][0], wf[NH][j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8 xb = __builtin_shufflevector(xf[i][0], xf[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        // formats 0 = E4M3 for both operands; scale operands 0 select the unscaled encoding (block scales of 1)
         acc[2 * NH + j][4 * MH + i] =
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[NH][j][kk], xf[i][kk], acc[2 * NH + j][4 * MH + i], 0, 0, 0);
+            __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb, acc[2 * NH + j][4 * MH + i], 0, 0, 0, 0, 0, 0);
+      }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[2 * NH + j][4 * MH + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, wf[NH][j][kk]), __builtin_bit_cast(bf16x8, xf[i][kk]),
+              acc[2 * NH + j][4 * MH + i], 0, 0, 0);
+  }
   __builtin_amdgcn_s_setprio(0);
 }
 
@@ -56,8 +79,9 @@ __device__ __forceinline__ void wait_units_in_flight(int units) {  // 2 DMA inst
 // its two waves ready.  Costs a second barrier per phase; LDS hazards hold because every unit is overwritten 7 phases
 // (14 segments) after... see the window derivation in DESIGN.md: last read of the old occupant at segment 2P-15, first
 // DMA of the new one at 2P-14; the retiring wait of the late half moves from after its multiply to after its load segment.
-template <int EPI, bool STAGGER>
+template <int EPI, bool STAGGER, bool FP8>
 __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
+  constexpr int ES = FP8 ? 1 : 2;  // bytes per operand element; a K tile is 128 bytes of every row either way
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,23 +98,23 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
                         (w >> 2) * 64 + (w & 3) * 8,     // U1: weight rows {0..31, 64..95} (+128)
                         (w >> 2) * 64 + (w & 3) * 8 + 32,  // U2: weight rows {32..63, 96..127} (+128)
                         64 + 8 * w};                     // U3: activation rows 64..127 (+128)
-  const bf16* usrc[4][2];
+  const char* usrc[4][2];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = ubase[k] + r8 + 128 * j;
       const int lc = p ^ ((row >> 1) & 7);
-      usrc[k][j] = (k == 1 || k == 2) ? a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + lc * 8
-                                      : a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx + lc * 8;
+      usrc[k][j] = (k == 1 || k == 2) ? (const char*)a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw * ES + lc * 16
+                                      : (const char*)a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx * ES + lc * 16;
     }
-  const int nk = a.K / BK;
+  const int nk = a.K * ES / 128;
   auto issue = [&](auto kind, int t) {  // unit (t, kind): 2 LDS-DMA instructions per thread
     constexpr int k = decltype(kind)::value;
     if (t < nk) {
       char* st = smem + (t & 1) * STAGE + ((k == 1 || k == 2) ? TILE : 0) + ubase[k] * 128;
-      __builtin_amdgcn_global_load_lds((const void*)(usrc[k][0] + t * BK), LDS_PTR(st), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const void*)(usrc[k][1] + t * BK), LDS_PTR(st + 128 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)(usrc[k][0] + t * 128), LDS_PTR(st), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)(usrc[k][1] + t * 128), LDS_PTR(st + 128 * 128), 16, 0, 0);
     }
   };
   using K0 = std::integral_constant<int, 0>;
@@ -109,20 +133,20 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   const int sw = (c >> 1) & 7;
   const int xrow0 = (128 * wr + c) * 128;          // + (64 mh + 16 i) * 128
   const int wrow0 = TILE + (64 * wc + c) * 128;    // + (32 nh + 16 j) * 128
-  bf16x8 xf[4][2], wf[2][2][2];
+  i32x4 xf[4][2], wf[2][2][2];
   auto read_x = [&](const char* st, int mh) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
-        xf[i][kk] = *(const bf16x8*)(st + xrow0 + (64 * mh + 16 * i) * 128 + (((kk * 4 + q) ^ sw) << 4));
+        xf[i][kk] = *(const i32x4*)(st + xrow0 + (64 * mh + 16 * i) * 128 + (((kk * 4 + q) ^ sw) << 4));
   };
-  auto read_w = [&](const char* st, int nh, bf16x8 (&dst)[2][2]) {
+  auto read_w = [&](const char* st, int nh, i32x4 (&dst)[2][2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
-        dst[j][kk] = *(const bf16x8*)(st + wrow0 + (32 * nh + 16 * j) * 128 + (((kk * 4 + q) ^ sw) << 4));
+        dst[j][kk] = *(const i32x4*)(st + wrow0 + (32 * nh + 16 * j) * 128 + (((kk * 4 + q) ^ sw) << 4));
   };
   auto phase_end = [&]() {
     __builtin_amdgcn_s_barrier();
@@ -143,21 +167,21 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
       read_x(st, 0);
       read_w(st, 0, wf[0]);
       issue(K3{}, t + 1);  // unit P + 7
-      quadrant_mma<0, 0>(acc, wf, xf);
+      quadrant_mma<FP8, 0, 0>(acc, wf, xf);
       phase_end();
       // ph1: (m0, n1)
       read_w(st, 1, wf[1]);
       issue(K0{}, t + 2);
-      quadrant_mma<0, 1>(acc, wf, xf);
+      quadrant_mma<FP8, 0, 1>(acc, wf, xf);
       phase_end();
       // ph2: (m1, n1)
       read_x(st, 1);
       issue(K1{}, t + 2);
-      quadrant_mma<1, 1>(acc, wf, xf);
+      quadrant_mma<FP8, 1, 1>(acc, wf, xf);
       phase_end();
       // ph3: (m1, n0); retire K tile t+1, keep the units issued behind it in flight
       issue(K2{}, t + 2);
-      quadrant_mma<1, 0>(acc, wf, xf);
+      quadrant_mma<FP8, 1, 0>(acc, wf, xf);
       wait_units_in_flight(max(0, min(3, total_units - 1 - (P + 7))));
       phase_end();
     }
@@ -171,22 +195,22 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
       read_w(st, 0, wf[0]);
       issue(K3{}, t + 1);
       phase_end();
-      quadrant_mma<0, 0>(acc, wf, xf);
+      quadrant_mma<FP8, 0, 0>(acc, wf, xf);
       phase_end();
       read_w(st, 1, wf[1]);
       issue(K0{}, t + 2);
       phase_end();
-      quadrant_mma<0, 1>(acc, wf, xf);
+      quadrant_mma<FP8, 0, 1>(acc, wf, xf);
       phase_end();
       read_x(st, 1);
       issue(K1{}, t + 2);
       phase_end();
-      quadrant_mma<1, 1>(acc, wf, xf);
+      quadrant_mma<FP8, 1, 1>(acc, wf, xf);
       phase_end();
       issue(K2{}, t + 2);
       if (late) wait_units_in_flight(keep);
       phase_end();
-      quadrant_mma<1, 0>(acc, wf, xf);
+      quadrant_mma<FP8, 1, 0>(acc, wf, xf);
       if (!late) wait_units_in_flight(keep);
       phase_end();
     }
@@ -194,6 +218,20 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   }
 
   // ---- epilogue: lane (c,q) of tile (nt,mt) holds out[m0 + 128wr + 16mt + c][n0 + 64wc + 16nt + 4q .. +3]
+  if constexpr (FP8) {
+    float xs[8];
+    f32x4 ws[4];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) xs[mt] = a.xscale[min(m0 + 128 * wr + 16 * mt + c, a.M - 1)];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) ws[nt] = *(const f32x4*)(a.wscale + min(n0 + 64 * wc + 16 * nt + 4 * q, a.N - 4));
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[nt][mt][r] *= ws[nt][r] * xs[mt];
+  }
   if constexpr (is_glu<EPI>) {
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
@@ -250,38 +288,46 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   }
 }
 
-template <int EPI, bool STAGGER>
+template <int EPI, bool STAGGER, bool FP8>
 void launch_one(const WideArgs& b, hipStream_t st) {
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)gemm_wide256_kernel<EPI, STAGGER>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_wide256_kernel<EPI, STAGGER, FP8>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     done = true;
   }
-  hipLaunchKernelGGL((gemm_wide256_kernel<EPI, STAGGER>), dim3(b.tilesM * b.tilesN), dim3(512), LDS_BYTES, st, b);
+  hipLaunchKernelGGL((gemm_wide256_kernel<EPI, STAGGER, FP8>), dim3(b.tilesM * b.tilesN), dim3(512), LDS_BYTES, st, b);
 }
-template <int EPI>
+template <int EPI, bool FP8>
 void launch(const WideArgs& a, hipStream_t st) {
   static const int variant = [] { const char* e = getenv("HWOCR_GEMM256"); return e ? atoi(e) : 2; }();
   WideArgs b = a;
   b.tilesM = (a.M + BM - 1) / BM;
   b.tilesN = (a.N + BN - 1) / BN;
-  if (variant == 1) launch_one<EPI, false>(b, st);
-  else launch_one<EPI, true>(b, st);
+  if (variant == 1) launch_one<EPI, false, FP8>(b, st);
+  else launch_one<EPI, true, FP8>(b, st);
+}
+template <bool FP8>
+int dispatch(const WideArgs& a, int epi, hipStream_t stream) {
+  switch (epi) {
+    case EPI_LINEAR: launch<EPI_LINEAR, FP8>(a, stream); break;
+    case EPI_RESIDUAL: launch<EPI_RESIDUAL, FP8>(a, stream); break;
+    case EPI_QUICKGELU: launch<EPI_QUICKGELU, FP8>(a, stream); break;
+    case EPI_GELU: launch<EPI_GELU, FP8>(a, stream); break;
+    case EPI_SWIGLU: launch<EPI_SWIGLU, FP8>(a, stream); break;
+    case EPI_GELU_TANH: launch<EPI_GELU_TANH, FP8>(a, stream); break;
+    case EPI_GEGLU: launch<EPI_GEGLU, FP8>(a, stream); break;
+    default: return HWOCR_EINVAL;
+  }
+  return hwocr_launch_status();
 }
 
 }  // namespace
 
-int hwocr_gemm_wide256(const WideArgs& a, int epi, hipStream_t stream) {
-  switch (epi) {
-    case EPI_LINEAR: launch<EPI_LINEAR>(a, stream); break;
-    case EPI_RESIDUAL: launch<EPI_RESIDUAL>(a, stream); break;
-    case EPI_QUICKGELU: launch<EPI_QUICKGELU>(a, stream); break;
-    case EPI_GELU: launch<EPI_GELU>(a, stream); break;
-    case EPI_SWIGLU: launch<EPI_SWIGLU>(a, stream); break;
-    case EPI_GELU_TANH: launch<EPI_GELU_TANH>(a, stream); break;
-    case EPI_GEGLU: launch<EPI_GEGLU>(a, stream); break;
-    default: return HWOCR_EINVAL;
-  }
-  return hwocr_launch_status();
+int hwocr_gemm_wide256(const WideArgs& a, int epi, hipStream_t stream) { return dispatch<false>(a, epi, stream); }
+
+// X and W hold E4M3 bytes (ldx / ldw / K in elements = bytes), a.xscale / a.wscale their per-row fp32 scales
+int hwocr_gemm_wide256_fp8(const WideArgs& a, int epi, hipStream_t stream) {
+  if (!a.xscale || !a.wscale || (a.K % 128) || (a.ldx % 16) || (a.ldw % 16) || a.N < 4) return HWOCR_EINVAL;
+  return dispatch<true>(a, epi, stream);
 }

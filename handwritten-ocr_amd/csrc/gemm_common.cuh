@@ -39,6 +39,8 @@ template <int EPI> __device__ __forceinline__ float glu_gate(float g) {
 struct WideArgs {
   const bf16* X; const bf16* W; const bf16* bias; const bf16* res; bf16* out;
   int M, N, K, ldx, ldw, ldo, ldres, tilesM, tilesN;
+  const float* xscale = nullptr;  // fp8 operands only (gemm256.hip): one scale per activation row / weight row
+  const float* wscale = nullptr;
 };
 
 // One 16x16 MFMA tile whose A operand was the weight tile: the lane holds out[m][n .. n+3] (4 consecutive features).
@@ -114,3 +116,4 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream);
 
 // launcher of the 256x256 kernel (gemm256.hip); returns HWOCR_EINVAL when the shape does not qualify
 int hwocr_gemm_wide256(const gemm::WideArgs& a, int epi, hipStream_t stream);
+int hwocr_gemm_wide256_fp8(const gemm::WideArgs& a, int epi, hipStream_t stream);

@@ -43,9 +43,19 @@ inline int pick_splitk_stream(int K, int N) {
   const int per = (ktiles + s - 1) / s;  // every slice must own at least one K tile
   return (ktiles + per - 1) / per;
 }
+// One wide GEMM of the read path (ldx == ldw == K everywhere).  With an E4M3 copy of the weight and K a multiple of 128
+// the activation rows are quantised into the workspace and the product runs on the fp8 MFMA; else bf16.
+inline int wide(const void* X, const void* W, const hwocr_w8& w8, void* q8, float* q8s, const void* bias, const void* res,
+                void* out, int M, int N, int K, int ldo, int ldres, int epi, hipStream_t st) {
+  if (w8.w && w8.scale && q8 && q8s && (K % 128) == 0 && (ldo % 8) == 0 && (ldres % 8) == 0) {
+    CHECK(hwocr_quant_rows_fp8(X, q8, q8s, M, K, K, K, st));
+    return hwocr_gemm_wide_fp8(q8, q8s, w8.w, w8.scale, bias, res, out, M, N, K, K, K, ldo, ldres, epi, st);
+  }
+  return hwocr_gemm_wide(X, W, bias, res, out, M, N, K, K, K, ldo, ldres, epi, st);
+}
 }  // namespace
 
-extern "C" int hwocr_abi_version(void) { return 4; }
+extern "C" int hwocr_abi_version(void) { return 5; }
 
 static char g_last_error[256] = "";
 extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text) {
@@ -85,8 +95,8 @@ extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, con
   for (int l = 0; l < m->depth; ++l) {
     const hwocr_vit_block& b = m->blocks[l];
     CHECK(norm(b.ln1_w, b.ln1_b));
-    CHECK(hwocr_gemm_wide(ws->xn, b.qkv_w, b.qkv_b, nullptr, ws->qkv, rows, 3 * DH, D, D, D, 3 * DH, 0,
-                          HWOCR_EPI_LINEAR, st));
+    CHECK(wide(ws->xn, b.qkv_w, b.qkv8, ws->q8, ws->q8s, b.qkv_b, nullptr, ws->qkv, rows, 3 * DH, D, 3 * DH, 0,
+               HWOCR_EPI_LINEAR, st));
     CHECK(hwocr_vit_rope_split(ws->qkv, ws->q, ws->k, ws->vt, lay->pos_h, lay->pos_w, m->rope_cos, m->rope_sin, rows,
                                rows, m->heads, hd, st));
     if (v25 && b.windowed && lay->nwin > 0) {
@@ -100,17 +110,18 @@ extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, con
                                rows_per_img_ld, (long)hd * rows, rows,            // V^T [head][hd][rows]
                                (long)rows_per_img_ld * DH, DH, scale, 0, st));
     }
-    CHECK(hwocr_gemm_wide(ws->attn, b.proj_w, b.proj_b, ws->x, ws->x, rows, D, DH, DH, DH, D, D, HWOCR_EPI_RESIDUAL, st));
+    CHECK(wide(ws->attn, b.proj_w, b.proj8, ws->q8, ws->q8s, b.proj_b, ws->x, ws->x, rows, D, DH, D, D, HWOCR_EPI_RESIDUAL,
+               st));
     CHECK(norm(b.ln2_w, b.ln2_b));
     if (v25) {  // down(silu(gate(x)) * up(x)), all three with bias (HF modeling_qwen2_5_vl.py:84-96)
-      CHECK(hwocr_gemm_wide(ws->xn, b.fc1_w, b.fc1_b, nullptr, ws->mlp, rows, 2 * m->mlp_dim, D, D, D, m->mlp_dim, 0,
-                            HWOCR_EPI_SWIGLU, st));
+      CHECK(wide(ws->xn, b.fc1_w, b.fc18, ws->q8, ws->q8s, b.fc1_b, nullptr, ws->mlp, rows, 2 * m->mlp_dim, D, m->mlp_dim, 0,
+                 HWOCR_EPI_SWIGLU, st));
     } else {
-      CHECK(hwocr_gemm_wide(ws->xn, b.fc1_w, b.fc1_b, nullptr, ws->mlp, rows, m->mlp_dim, D, D, D, m->mlp_dim, 0,
-                            sig ? HWOCR_EPI_GELU_TANH : HWOCR_EPI_QUICKGELU, st));
+      CHECK(wide(ws->xn, b.fc1_w, b.fc18, ws->q8, ws->q8s, b.fc1_b, nullptr, ws->mlp, rows, m->mlp_dim, D, m->mlp_dim, 0,
+                 sig ? HWOCR_EPI_GELU_TANH : HWOCR_EPI_QUICKGELU, st));
     }
-    CHECK(hwocr_gemm_wide(ws->mlp, b.fc2_w, b.fc2_b, ws->x, ws->x, rows, D, m->mlp_dim, m->mlp_dim, m->mlp_dim, D, D,
-                          HWOCR_EPI_RESIDUAL, st));
+    CHECK(wide(ws->mlp, b.fc2_w, b.fc28, ws->q8, ws->q8s, b.fc2_b, ws->x, ws->x, rows, D, m->mlp_dim, D, D,
+               HWOCR_EPI_RESIDUAL, st));
   }
   // patch merger: norm -> view(-1, merge^2 * D) -> Linear -> GELU -> Linear; SigLIP: post_layernorm -> one projector
   CHECK(norm(m->merger_ln_w, m->merger_ln_b));
@@ -144,8 +155,8 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
     bf16* Vc = B(kv->vt) + l * k_layer + seq0 * k_seq;
     CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.in_norm_w, ws->hn, Hd, nullptr, rows, Hd, m->eps,
                             G, st));
-    CHECK(hwocr_gemm_wide(ws->hn, L.qkv_w, L.qkv_b, nullptr, ws->qkv, rows, QW, Hd, Hd, Hd, QW, 0, HWOCR_EPI_LINEAR,
-                          st));
+    CHECK(wide(ws->hn, L.qkv_w, L.qkv8, ws->q8, ws->q8s, L.qkv_b, nullptr, ws->qkv, rows, QW, Hd, QW, 0, HWOCR_EPI_LINEAR,
+               st));
     CHECK(hwocr_mrope_kv_prefill(ws->qkv, ws->q, Kc, Vc, pos3, m->rope_cos, m->rope_sin, rows, rows_per_seq, m->Hq,
                                  m->Hkv, m->sec0, m->sec1, k_seq, k_head, k_seq, k_head, kv->ctx, HD, kv->tiled, st));
     // Gemma (PaliGemma): the whole prompt is a bidirectional prefix; Qwen: causal
@@ -153,14 +164,14 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
                              (long)rows_per_seq * m->Hq * HD, HD, (long)m->Hq * HD,  // Q [row][Hq][128]
                              k_seq, k_head, HD, k_seq, k_head, kv->ctx,
                              (long)rows_per_seq * m->Hq * HD, (long)m->Hq * HD, scale, kv->tiled, st));
-    CHECK(hwocr_gemm_wide(ws->attn, L.o_w, nullptr, ws->h, ws->h, rows, Hd, m->Hq * HD, m->Hq * HD, m->Hq * HD, Hd, Hd,
-                          HWOCR_EPI_RESIDUAL, st));
+    CHECK(wide(ws->attn, L.o_w, L.o8, ws->q8, ws->q8s, nullptr, ws->h, ws->h, rows, Hd, m->Hq * HD, Hd, Hd,
+               HWOCR_EPI_RESIDUAL, st));
     CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd, nullptr, rows, Hd,
                             m->eps, G, st));
-    CHECK(hwocr_gemm_wide(ws->hn, L.gate_up_w, nullptr, nullptr, ws->act, rows, 2 * m->inter, Hd, Hd, Hd, m->inter, 0,
-                          G ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, st));
-    CHECK(hwocr_gemm_wide(ws->act, L.down_w, nullptr, ws->h, ws->h, rows, Hd, m->inter, m->inter, m->inter, Hd, Hd,
-                          HWOCR_EPI_RESIDUAL, st));
+    CHECK(wide(ws->hn, L.gate_up_w, L.gate_up8, ws->q8, ws->q8s, nullptr, nullptr, ws->act, rows, 2 * m->inter, Hd, m->inter,
+               0, G ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, st));
+    CHECK(wide(ws->act, L.down_w, L.down8, ws->q8, ws->q8s, nullptr, ws->h, ws->h, rows, Hd, m->inter, Hd, Hd,
+               HWOCR_EPI_RESIDUAL, st));
   }
   // final norm on the last prompt token of every read -> LM head -> first generated token
   CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->final_norm_w, ws->hn, Hd, last_rows, nseq, Hd,

@@ -315,7 +315,9 @@ def _ceil(x: int, m: int) -> int:
 
 class ReadEngine:
     def __init__(self, cfg: ModelConfig, state_dict: dict, max_reads: int = 96, ctx: int = 2048, device: str = "cuda:0",
-                 vit_batch: int = 8, prefill_batch: int = 16, attn_splits: int = 0):
+                 vit_batch: int = 8, prefill_batch: int = 16, attn_splits: int = 0, fp8: bool = False):
+        """fp8: run the wide GEMMs of the vision tower and of the decoder prefill (K a multiple of 128) on E4M3 copies of
+        the weights with per-token activation scales (BASELINE config 4); norms, attention, decode steps stay bf16."""
         cfg.validate()
         if not torch.cuda.is_available():
             raise _lib.HwocrError("ReadEngine needs an MI355X (ROCm) device: there is no CPU path")
@@ -330,6 +332,7 @@ class ReadEngine:
         self.vit_batch = vit_batch
         self.prefill_batch = prefill_batch
         self.attn_splits = attn_splits
+        self.fp8 = bool(fp8)
         self.collect_timings = False
         self.timings = {}
         self._keep = []  # everything the C structs point at
@@ -351,6 +354,18 @@ class ReadEngine:
                    "hwocr_tile_weights")
         self._tiled_keep.append(out)
         return out
+
+    def _w8(self, w2d: torch.Tensor) -> _lib.W8:
+        """E4M3 copy of a bound [N][K] weight + per-row scales (hwocr_quant_rows_fp8), or the empty pack."""
+        n, k = w2d.shape
+        if not self.fp8 or k % 128 or n % 8:
+            return _lib.W8()
+        q = torch.empty(n, k, dtype=torch.uint8, device=self.dev)
+        s = torch.empty(n, dtype=torch.float32, device=self.dev)
+        _lib.check(self.lib.hwocr_quant_rows_fp8(_lib.ptr(w2d), _lib.ptr(q), _lib.ptr(s), n, k, k, k, _lib.stream_handle()),
+                   "hwocr_quant_rows_fp8")
+        self._keep += [q, s]
+        return _lib.W8(w=_lib.ptr(q), scale=_lib.ptr(s))
 
     def _bind_weights(self, sd: dict) -> None:
         if self.cfg.family == "paligemma":
@@ -396,10 +411,13 @@ class ReadEngine:
             B = blocks[l]
             B.ln1_w, B.ln1_b = P(self._t(sd[b + "layer_norm1.weight"])), P(self._t(sd[b + "layer_norm1.bias"]))
             B.ln2_w, B.ln2_b = P(self._t(sd[b + "layer_norm2.weight"])), P(self._t(sd[b + "layer_norm2.bias"]))
-            B.qkv_w, B.qkv_b = P(self._t(qkv_w)), P(self._t(qkv_b))
-            B.proj_w, B.proj_b = P(self._t(proj_w.reshape(D, Hn * hp))), P(self._t(sd[b + "self_attn.out_proj.bias"]))
-            B.fc1_w, B.fc1_b = P(self._t(pad_rows(sd[b + "mlp.fc1.weight"], c.mlp_dim))), P(self._t(pad_rows(sd[b + "mlp.fc1.bias"], c.mlp_dim)))
-            B.fc2_w, B.fc2_b = P(self._t(fc2)), P(self._t(sd[b + "mlp.fc2.bias"]))
+            w_qkv, w_proj = self._t(qkv_w), self._t(proj_w.reshape(D, Hn * hp))
+            w_fc1, w_fc2 = self._t(pad_rows(sd[b + "mlp.fc1.weight"], c.mlp_dim)), self._t(fc2)
+            B.qkv_w, B.qkv_b = P(w_qkv), P(self._t(qkv_b))
+            B.proj_w, B.proj_b = P(w_proj), P(self._t(sd[b + "self_attn.out_proj.bias"]))
+            B.fc1_w, B.fc1_b = P(w_fc1), P(self._t(pad_rows(sd[b + "mlp.fc1.bias"], c.mlp_dim)))
+            B.fc2_w, B.fc2_b = P(w_fc2), P(self._t(sd[b + "mlp.fc2.bias"]))
+            B.qkv8, B.proj8, B.fc18, B.fc28 = self._w8(w_qkv), self._w8(w_proj), self._w8(w_fc1), self._w8(w_fc2)
         # identity rotation table for the (unused) rotary of the shared rope/split kernel: row 0 = (cos 1, sin 0)
         self.vit_cos = torch.ones(8, hp // 4, dtype=torch.float32, device=dev)
         self.vit_sin = torch.zeros(8, hp // 4, dtype=torch.float32, device=dev)
@@ -430,8 +448,10 @@ class ReadEngine:
                       ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"), ("ln2_w", "norm2.weight"))
             v2 = (("ln1_b", "norm1.bias"), ("ln2_b", "norm2.bias"), ("fc1_w", "mlp.fc1.weight"), ("fc1_b", "mlp.fc1.bias"),
                   ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias"))
+            bound = {}
             for fld, key in common + (() if v25 else v2):
-                setattr(blocks[l], fld, P(self._t(sd[b + key])))
+                bound[fld] = self._t(sd[b + key])
+                setattr(blocks[l], fld, P(bound[fld]))
             if v25:
                 # gate/up (+ biases) zero-padded to mlp_dim rows and interleaved in 16-row tiles for the SwiGLU epilogue;
                 # padded rows give silu(0) * 0 = 0 and meet zero columns of down_proj
@@ -451,10 +471,14 @@ class ReadEngine:
 
                 down = torch.zeros(D, Ip, dtype=torch.bfloat16, device=self.dev)
                 down[:, :I] = sd[b + "mlp.down_proj.weight"].to(self.dev, torch.bfloat16)
-                blocks[l].fc1_w = P(self._t(interleave(sd[b + "mlp.gate_proj.weight"], sd[b + "mlp.up_proj.weight"])))
+                bound["fc1_w"] = self._t(interleave(sd[b + "mlp.gate_proj.weight"], sd[b + "mlp.up_proj.weight"]))
+                bound["fc2_w"] = self._t(down)
+                blocks[l].fc1_w = P(bound["fc1_w"])
                 blocks[l].fc1_b = P(self._t(interleave(sd[b + "mlp.gate_proj.bias"], sd[b + "mlp.up_proj.bias"])))
-                blocks[l].fc2_w, blocks[l].fc2_b = P(self._t(down)), P(self._t(sd[b + "mlp.down_proj.bias"]))
+                blocks[l].fc2_w, blocks[l].fc2_b = P(bound["fc2_w"]), P(self._t(sd[b + "mlp.down_proj.bias"]))
                 blocks[l].windowed = 0 if l in c.fullatt else 1
+            blocks[l].qkv8, blocks[l].proj8 = self._w8(bound["qkv_w"]), self._w8(bound["proj_w"])
+            blocks[l].fc18, blocks[l].fc28 = self._w8(bound["fc1_w"]), self._w8(bound["fc2_w"])
         # vision rotary table, fp32, exactly as the library builds it (positions * inv_freq, then cos/sin)
         hd = c.vit_hd
         inv = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float) / (hd // 2)))
@@ -497,6 +521,7 @@ class ReadEngine:
             # decode copies in MFMA-fragment order (contiguous KiB per fragment load; 288 GB of HBM pays for the copy)
             L.qkv_wt, L.o_wt = P(self._tiled(w_qkv)), P(self._tiled(w_o))
             L.gate_up_wt, L.down_wt = P(self._tiled(w_gu)), P(self._tiled(w_down))
+            L.qkv8, L.o8, L.gate_up8, L.down8 = self._w8(w_qkv), self._w8(w_o), self._w8(w_gu), self._w8(w_down)
         embed = self._t(sd[t + "embed_tokens.weight"])
         head = embed if (c.tie or "lm_head.weight" not in sd) else self._t(sd["lm_head.weight"])
         inv = 1.0 / (c.rope_theta ** (torch.arange(0, HD, 2, dtype=torch.float) / HD))
@@ -555,6 +580,9 @@ class ReadEngine:
                 part_o=torch.empty(R * c.q_heads * splits * HD, dtype=torch.float32, device=dev),
                 part_ml=torch.empty(R * c.q_heads * splits * 2, dtype=torch.float32, device=dev),
                 logits=torch.empty(R, c.vocab, dtype=bf, device=dev))
+            if self.fp8:  # E4M3 staging of one prefill GEMM input + its row scales
+                self._bufs["q8"] = torch.empty(rows * max(c.hidden, c.q_heads * HD, c.inter), dtype=torch.uint8, device=dev)
+                self._bufs["q8s"] = torch.empty(rows, dtype=torch.float32, device=dev)
             self._ws_rows = rows
             self._ws_dec = _lib.DecWs(**{k: _lib.ptr(v) for k, v in self._bufs.items()})
             self._drop_graphs()  # graphs bake workspace pointers
@@ -572,6 +600,9 @@ class ReadEngine:
                 vt=torch.zeros(rows * DH + 64, dtype=bf, device=dev), attn=torch.empty(rows, DH, dtype=bf, device=dev),
                 mlp=torch.empty(rows, c.mlp_dim, dtype=bf, device=dev),
                 merge_mid=torch.empty(rows // mm, D * mm, dtype=bf, device=dev))
+            if self.fp8:
+                self._vbufs["q8"] = torch.empty(rows * max(D, DH, c.mlp_dim), dtype=torch.uint8, device=dev)
+                self._vbufs["q8s"] = torch.empty(rows, dtype=torch.float32, device=dev)
             self._vit_rows = rows
             self._vws = _lib.VitWs(**{k: _lib.ptr(v) for k, v in self._vbufs.items()})
             self._vit_layout = None

@@ -49,6 +49,16 @@ const char* hwocr_last_error(void);
 int hwocr_gemm_wide(const void* X, const void* W, const void* bias, const void* res, void* out, int M, int N, int K,
                     int ldx, int ldw, int ldo, int ldres, int epi, hwocr_stream_t stream);
 
+/* E4M3 path of the wide GEMM (BASELINE config 4: "fp8 MFMA on CDNA4"; no reference counterpart — HF runs bf16).
+ * hwocr_quant_rows_fp8: per row, scale = max|x| / 448 (1 for an all-zero row), Q = e4m3(x * (448 / max|x|)) with
+ * round-to-nearest-even; used for activations (per token) and, once at load time, for weights (per output feature).
+ * hwocr_gemm_wide_fp8: out = epi(xscale[m] * wscale[n] * sum_k X8[m][k] W8[n][k]) on v_mfma_f32_16x16x128_f8f6f4 with fp32
+ * accumulation; bias / res / out stay bf16 and the epilogues are those of hwocr_gemm_wide.  K % 128 == 0, N % 8 == 0. */
+int hwocr_quant_rows_fp8(const void* X, void* Q, float* scale, int rows, int K, int ldx, int ldq, hwocr_stream_t stream);
+int hwocr_gemm_wide_fp8(const void* X8, const float* xscale, const void* W8, const float* wscale, const void* bias,
+                        const void* res, void* out, int M, int N, int K, int ldx, int ldw, int ldo, int ldres, int epi,
+                        hwocr_stream_t stream);
+
 /* Same contraction for <= 256 rows (decode).  epi PARTIAL writes fp32 slabs out[splitk][Bsz][ldo].
  * w_tiled != 0: W is the fragment-tiled copy made by hwocr_tile_weights (ldw ignored). */
 int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out, int Bsz, int N, int K, int ldx,
@@ -129,11 +139,16 @@ int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_
 #define HWOCR_VIT_SIGLIP 2  /* PaliGemma tower: biased patch conv + learned positions, LayerNorm, fc1 -> tanh GELU -> fc2, no rotary,
                              * post-LayerNorm, one linear projector (HF siglip/modeling_siglip.py:116-356, paligemma/modeling_paligemma.py:90-98) */
 
+/* E4M3 copy of one weight matrix, [N][K] bytes + one fp32 scale per row (hwocr_quant_rows_fp8 of the bf16 matrix);
+ * w == NULL: that GEMM stays in bf16 */
+typedef struct { const void* w; const float* scale; } hwocr_w8;
+
 typedef struct {
   /* QWEN2_5: ln*_b unused; fc1_w/fc1_b = gate_proj/up_proj rows interleaved in 16-row tiles [2*mlp_dim][dim] (+ bias
    * likewise), fc2 = down_proj [dim][mlp_dim]; mlp_dim is the intermediate size zero-padded to a multiple of 64 */
   const void *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
   int windowed; /* QWEN2_5: attention inside windows (layer not in fullatt_block_indexes) */
+  hwocr_w8 qkv8, proj8, fc18, fc28; /* optional E4M3 copies of qkv_w / proj_w / fc1_w / fc2_w (used when K % 128 == 0) */
 } hwocr_vit_block;
 
 typedef struct {
@@ -151,6 +166,8 @@ typedef struct {
 
 typedef struct { /* all device buffers, rows = nimg * rows_per_img_ld; vt holds 64 elements of slack past rows*dim */
   void *patches, *x, *xn, *qkv, *q, *k, *vt, *attn, *mlp, *merge_mid;
+  void* q8;   /* E4M3 staging of one GEMM input, rows * max(dim, heads*head width, mlp_dim) bytes; NULL without fp8 weights */
+  float* q8s; /* its row scales [rows] */
 } hwocr_vit_ws;
 
 typedef struct { /* device index tables of one batch of equally sized pages */
@@ -169,6 +186,7 @@ int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, const void* im
 typedef struct {
   const void *in_norm_w, *qkv_w, *qkv_b, *o_w, *post_norm_w, *gate_up_w, *down_w;
   const void *qkv_wt, *o_wt, *gate_up_wt, *down_wt; /* fragment-tiled copies for decode (NULL: use the row-major ones) */
+  hwocr_w8 qkv8, o8, gate_up8, down8; /* optional E4M3 copies for the prefill GEMMs (decode steps stay bf16) */
 } hwocr_dec_layer;
 
 typedef struct {
@@ -195,6 +213,8 @@ typedef struct {
   float *slabs;                           /* fp32 split-K slabs (decode) */
   float *part_o, *part_ml;                /* decode attention partials */
   void *logits;                           /* bf16 [nseq][vocab] */
+  void* q8;                               /* E4M3 staging of one prefill GEMM input, rows * max(hidden, Hq*head_dim, inter) bytes, or NULL */
+  float* q8s;                             /* its row scales [rows] */
 } hwocr_dec_ws;
 
 typedef struct {
@@ -221,7 +241,8 @@ int hwocr_decode_graph_create(const hwocr_decoder* m, const hwocr_dec_ws* ws, co
 int hwocr_decode_graph_launch(void* graph, int n, hwocr_stream_t stream);
 int hwocr_decode_graph_destroy(void* graph);
 
-/* bench instrumentation: HIP events on the launch stream around every hwocr_gemm_wide launch while enabled */
+/* bench instrumentation: HIP events on the launch stream around every hwocr_gemm_wide (on == 1) or hwocr_gemm_wide_fp8
+ * (on == 2) launch while enabled */
 int hwocr_profile_enable(int on);
 int hwocr_profile_read(double* total_ms, double* total_flops, long* launches);
 

@@ -575,3 +575,79 @@ def test_argmax_repetition_penalty():
                                       p(seen), V // 32, 1.0, st()) == 0
     sync()
     assert cur.tolist()[:2] == [40, 7]
+
+
+# ---------------------------------------------------------------------------------------------- fp8 (E4M3) wide GEMM
+def _quant_gpu(x):
+    rows, K = x.shape
+    q = torch.full((rows, K), 0x7F, dtype=torch.uint8, device=DEV)  # NaN pattern: every byte must be overwritten
+    s = torch.full((rows,), float("nan"), dtype=torch.float32, device=DEV)
+    assert lib().hwocr_quant_rows_fp8(p(x), p(q), p(s), rows, K, K, K, st()) == 0
+    sync()
+    return q, s
+
+
+@pytest.mark.parametrize("rows,K", [(1, 128), (37, 1152), (260, 4352), (5, 16384)])
+def test_quant_rows_fp8_bit_exact(rows, K):
+    from oracle import fp8_ref
+    x = randbf(rows, K, scale=2.0, seed=11)
+    x[0, : K // 2] *= 40.0                      # wide dynamic range inside one row: subnormal codes appear
+    if rows > 2:
+        x[2] = 0                                # all-zero row: scale 1, codes 0
+    q, s = _quant_gpu(x)
+    wq, ws = fp8_ref.quant_rows(x.cpu())
+    assert torch.equal(s.cpu(), ws), "row scales differ"
+    assert torch.equal(q.cpu(), wq.view(torch.uint8)), "E4M3 codes differ"
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (300, 264, 256), (1000, 384, 1152), (2065, 1024, 640), (4096, 1152, 4352)])
+@pytest.mark.parametrize("epi", [0, 1, 6])
+def test_gemm_wide_fp8(M, N, K, epi):
+    """The kernel against the exact scaled product of the SAME codes (oracle/fp8_ref.py): only fp32 accumulation order and
+    the bf16 epilogue rounding separate them."""
+    from oracle import fp8_ref
+    x = randbf(M, K, scale=1.0, seed=21)
+    w = randbf(N, K, scale=K ** -0.5, seed=22)
+    bias = randbf(N, scale=0.5, seed=23)
+    res = randbf(M, N, seed=24)
+    xq, xs = _quant_gpu(x)
+    wq, ws = _quant_gpu(w)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rc = lib().hwocr_gemm_wide_fp8(p(xq), p(xs), p(wq), p(ws), p(bias), p(res) if epi == 1 else None, p(out), M, N, K, K, K, N,
+                                   N, epi, st())
+    assert rc == 0
+    sync()
+    acc = fp8_ref.gemm(xq.cpu().view(torch.float8_e4m3fn), xs.cpu(), wq.cpu().view(torch.float8_e4m3fn), ws.cpu()).to(DEV)
+    want = _epilogue_ref(acc, bias, res, epi)
+    mag = (acc + bias.float()).abs() + (res.float().abs() if epi == 1 else 0.0)
+    assert_close_bf16(out, want, ulps=2.0, atol=2e-3, what=f"gemm_wide_fp8 epi={epi}", mag=mag)
+    # and the quantisation itself stays where E4M3 puts it: a few percent of the bf16 product's spread
+    exact = x.float() @ w.float().t()
+    assert float((acc - exact).abs().mean() / exact.abs().mean()) < 0.06
+
+
+@pytest.mark.parametrize("geglu", [False, True])
+def test_gemm_wide_fp8_gated(geglu):
+    from oracle import fp8_ref
+    M, N, K = 1328, 1792, 1536
+    x = randbf(M, K, seed=25)
+    w = randbf(N, K, scale=K ** -0.5, seed=26)
+    xq, xs = _quant_gpu(x)
+    wq, ws = _quant_gpu(w)
+    out = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert lib().hwocr_gemm_wide_fp8(p(xq), p(xs), p(wq), p(ws), None, None, p(out), M, N, K, K, K, N // 2, 0, 7 if geglu else 4,
+                                     st()) == 0
+    sync()
+    acc = fp8_ref.gemm(xq.cpu().view(torch.float8_e4m3fn), xs.cpu(), wq.cpu().view(torch.float8_e4m3fn), ws.cpu()).to(DEV)
+    want = _swiglu_ref(acc, geglu=geglu)
+    gate = rbf(acc.view(M, N // 32, 2, 16)[:, :, 0, :]).reshape(M, N // 2)
+    assert_close_bf16(out, want, ulps=3.0, atol=2e-3, what="gemm_wide_fp8 gated", mag=want.abs() * (1.0 + gate.abs()))
+
+
+def test_gemm_wide_fp8_rejects_bad_shapes():
+    z = torch.zeros(256, 256, dtype=torch.uint8, device=DEV)
+    s = torch.ones(256, dtype=torch.float32, device=DEV)
+    o = torch.zeros(256, 256, dtype=torch.bfloat16, device=DEV)
+    assert lib().hwocr_gemm_wide_fp8(p(z), p(s), p(z), p(s), None, None, p(o), 256, 256, 192, 256, 256, 256, 0, 0, st()) == 1
+    assert lib().hwocr_gemm_wide_fp8(p(z), None, p(z), p(s), None, None, p(o), 256, 256, 256, 256, 256, 256, 0, 0, st()) == 1
+    assert lib().hwocr_quant_rows_fp8(p(o), p(z), p(s), 256, 100, 256, 256, st()) == 1
