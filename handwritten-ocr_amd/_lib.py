@@ -101,6 +101,8 @@ _HIP_SIGS = {
     "hwocr_last_error": ([], C.c_char_p),
     "hwocr_gemm_wide": ([P, P, P, P, P, I, I, I, I, I, I, I, I, P], I),
     "hwocr_quant_rows_fp8": ([P, P, P, I, I, I, I, P], I),
+    "hwocr_layernorm_fp8": ([P, P, P, P, P, I, I, I, I, F, P], I),
+    "hwocr_rmsnorm_fp8": ([P, I, P, P, P, I, I, I, F, I, P], I),
     "hwocr_gemm_wide_fp8": ([P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P], I),
     "hwocr_gemm_skinny": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "hwocr_tile_weights": ([P, P, I, I, I, P], I),

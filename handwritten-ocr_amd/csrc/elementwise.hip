@@ -58,7 +58,38 @@ __global__ __launch_bounds__(256) void patchify_kernel(PatchifyArgs a) {
 // LayerNorm (vision tower: HF modeling_qwen2_vl.py:428-429, merger ln_q :281).  fp32 statistics,
 // one rounding at the end, as nn.LayerNorm does on a bf16 tensor.
 // ------------------------------------------------------------------------------------------------
-struct LayerNormArgs { const bf16* x; const bf16* w; const bf16* b; bf16* out; int rows, D, ldx, ldo; float eps; };
+// E4M3 row emission shared by the row quantiser and the norms that feed an fp8 GEMM: the wave holds one row as bf16
+// chunks o[i] (chunk lane + 64 i); scale = max|o| / 448, codes = e4m3(o * (448 / max|o|)), round-to-nearest-even.
+__device__ __forceinline__ int2 e4m3_pack8(const bf16x8& v, float inv) {
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(bf2f(v[e]) * inv, -448.0f), 448.0f);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  return make_int2(lo, hi);
+}
+__device__ __forceinline__ void e4m3_emit_row(const bf16x8 (&o)[MAXC], int lane, int nch, unsigned char* dst, float* scale) {
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < nch)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf2f(o[i][e])));
+  amax = wave_max(amax);
+  const float inv = amax > 0.f ? 448.0f / amax : 0.f;
+  if (lane == 0) *scale = amax > 0.f ? amax / 448.0f : 1.0f;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i)
+    if (lane + 64 * i < nch) *(int2*)(dst + (lane + 64 * i) * 8) = e4m3_pack8(o[i], inv);
+}
+
+struct LayerNormArgs {
+  const bf16* x; const bf16* w; const bf16* b; bf16* out; int rows, D, ldx, ldo; float eps;
+  unsigned char* q8; float* q8s; int ldq;  // q8 != NULL: the bf16 row is not stored, its E4M3 codes + scale are
+};
 __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + w;
@@ -83,18 +114,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mean; ss += d * d; }
   const float rstd = 1.0f / sqrtf(wave_sum(ss) / a.D + a.eps);
+  bf16x8 o[MAXC];
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       const bf16x8 g = *(const bf16x8*)(a.w + ch * 8);
       const bf16x8 bb = *(const bf16x8*)(a.b + ch * 8);
-      bf16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = f2bf((x[i][e] - mean) * rstd * bf2f(g[e]) + bf2f(bb[e]));
-      *(bf16x8*)(a.out + (long)row * a.ldo + ch * 8) = o;
+      for (int e = 0; e < 8; ++e) o[i][e] = f2bf((x[i][e] - mean) * rstd * bf2f(g[e]) + bf2f(bb[e]));
+      if (!a.q8) *(bf16x8*)(a.out + (long)row * a.ldo + ch * 8) = o[i];
     }
   }
+  if (a.q8) e4m3_emit_row(o, lane, nch, a.q8 + (long)row * a.ldq, a.q8s + row);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -108,6 +140,7 @@ struct RmsArgs {
   const bf16* bias; bf16* h; int ldh;
   const bf16* w; bf16* out; int ldo;
   const int* row_index; int rows, D; float eps; int gemma;
+  unsigned char* q8 = nullptr; float* q8s = nullptr; int ldq = 0;  // add_rmsnorm_kernel only: E4M3 codes + scale instead of out
 };
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(RmsArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -149,20 +182,21 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(RmsArgs a) {
       for (int e = 0; e < 8; ++e) ss += x[i][e] * x[i][e];
     }
   }
-  if (!a.out) return;
+  if (!a.out && !a.q8) return;
   const float rstd = rsqrtf(wave_sum(ss) / a.D + a.eps);
+  bf16x8 o[MAXC];
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       const bf16x8 g = *(const bf16x8*)(a.w + ch * 8);
-      bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        o[e] = a.gemma ? f2bf(x[i][e] * rstd * (1.0f + bf2f(g[e]))) : f2bf(bf2f(g[e]) * rbf(x[i][e] * rstd));
-      *(bf16x8*)(a.out + (long)row * a.ldo + ch * 8) = o;
+        o[i][e] = a.gemma ? f2bf(x[i][e] * rstd * (1.0f + bf2f(g[e]))) : f2bf(bf2f(g[e]) * rbf(x[i][e] * rstd));
+      if (!a.q8) *(bf16x8*)(a.out + (long)row * a.ldo + ch * 8) = o[i];
     }
   }
+  if (a.q8) e4m3_emit_row(o, lane, nch, a.q8 + (long)row * a.ldq, a.q8s + row);
 }
 
 // Few rows (decode: one row per read): one workgroup of NT threads per row (256: D <= 2048, 512: D <= 4096), every
@@ -587,16 +621,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(QuantArgs a) {
   if (lane == 0) a.scale[row] = amax > 0.f ? amax / 448.0f : 1.0f;
   unsigned char* dst = a.q + (long)row * a.ldq;
   for (int ch = lane; ch < nch; ch += 64) {
-    const bf16x8 v = *(const bf16x8*)(src + ch * 8);
-    float f[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(bf2f(v[e]) * inv, -448.0f), 448.0f);
-    int lo = 0, hi = 0;
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
-    *(int2*)(dst + ch * 8) = make_int2(lo, hi);
+    *(int2*)(dst + ch * 8) = e4m3_pack8(*(const bf16x8*)(src + ch * 8), inv);
   }
 }
 
@@ -613,8 +638,27 @@ extern "C" int hwocr_layernorm(const void* x, const void* w, const void* b, void
                                int ldo, float eps, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldx % 8 || ldo % 8) return HWOCR_EINVAL;
-  LayerNormArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)out, rows, D, ldx, ldo, eps};
+  LayerNormArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)out, rows, D, ldx, ldo, eps, nullptr, nullptr, 0};
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_layernorm_fp8(const void* x, const void* w, const void* b, void* q8, float* q8s, int rows, int D,
+                                   int ldx, int ldq, float eps, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
+  if (!q8 || !q8s || rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldx % 8 || ldq % 8 || ldq < D) return HWOCR_EINVAL;
+  LayerNormArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)b, nullptr, rows, D, ldx, 0, eps, (unsigned char*)q8, q8s, ldq};
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_rmsnorm_fp8(const void* h, int ldh, const void* w, void* q8, float* q8s, int ldq, int rows, int D,
+                                 float eps, int gemma, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
+  if (!q8 || !q8s || rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldh % 8 || ldq % 8 || ldq < D) return HWOCR_EINVAL;
+  RmsArgs a{nullptr, 0, 0, 0, nullptr, (bf16*)h, ldh, (const bf16*)w, nullptr, 0, nullptr, rows, D, eps, gemma};
+  a.q8 = (unsigned char*)q8; a.q8s = q8s; a.ldq = ldq;
+  hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }
 

@@ -45,10 +45,14 @@ inline int pick_splitk_stream(int K, int N) {
 }
 // One wide GEMM of the read path (ldx == ldw == K everywhere).  With an E4M3 copy of the weight and K a multiple of 128
 // the activation rows are quantised into the workspace and the product runs on the fp8 MFMA; else bf16.
+inline bool runs_fp8(const hwocr_w8& w8, const void* q8, const float* q8s, int K) {
+  return w8.w && w8.scale && q8 && q8s && (K % 128) == 0;
+}
+// quantised: the producer (a norm) already left the E4M3 rows + scales of X in the workspace
 inline int wide(const void* X, const void* W, const hwocr_w8& w8, void* q8, float* q8s, const void* bias, const void* res,
-                void* out, int M, int N, int K, int ldo, int ldres, int epi, hipStream_t st) {
-  if (w8.w && w8.scale && q8 && q8s && (K % 128) == 0 && (ldo % 8) == 0 && (ldres % 8) == 0) {
-    CHECK(hwocr_quant_rows_fp8(X, q8, q8s, M, K, K, K, st));
+                void* out, int M, int N, int K, int ldo, int ldres, int epi, hipStream_t st, bool quantised = false) {
+  if (runs_fp8(w8, q8, q8s, K)) {
+    if (!quantised) CHECK(hwocr_quant_rows_fp8(X, q8, q8s, M, K, K, K, st));
     return hwocr_gemm_wide_fp8(q8, q8s, w8.w, w8.scale, bias, res, out, M, N, K, K, K, ldo, ldres, epi, st);
   }
   return hwocr_gemm_wide(X, W, bias, res, out, M, N, K, K, K, ldo, ldres, epi, st);
@@ -77,6 +81,11 @@ extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, con
     return v25 ? hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->x, D, w, ws->xn, D, nullptr, rows, D, m->eps, 0, st)
                : hwocr_layernorm(ws->x, w, b, ws->xn, rows, D, D, D, m->eps, st);
   };
+  // the same norm in front of a GEMM that runs in fp8: E4M3 rows + scales straight into the workspace
+  auto norm8 = [&](const void* w, const void* b) {
+    return v25 ? hwocr_rmsnorm_fp8(ws->x, D, w, ws->q8, ws->q8s, D, rows, D, m->eps, 0, st)
+               : hwocr_layernorm_fp8(ws->x, w, b, ws->q8, ws->q8s, rows, D, D, D, m->eps, st);
+  };
   CHECK(hwocr_patchify(images, m->pixel_lut, ws->patches, nimg, H, W, m->patch, m->merge, m->tps, m->kpad,
                        rows_per_img_ld, lay->row_src, st));
   if (sig) {
@@ -94,9 +103,10 @@ extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, con
   const float scale = 1.0f / sqrtf((float)(D / m->heads));
   for (int l = 0; l < m->depth; ++l) {
     const hwocr_vit_block& b = m->blocks[l];
-    CHECK(norm(b.ln1_w, b.ln1_b));
+    const bool q1 = runs_fp8(b.qkv8, ws->q8, ws->q8s, D), q2 = runs_fp8(b.fc18, ws->q8, ws->q8s, D);
+    CHECK(q1 ? norm8(b.ln1_w, b.ln1_b) : norm(b.ln1_w, b.ln1_b));
     CHECK(wide(ws->xn, b.qkv_w, b.qkv8, ws->q8, ws->q8s, b.qkv_b, nullptr, ws->qkv, rows, 3 * DH, D, 3 * DH, 0,
-               HWOCR_EPI_LINEAR, st));
+               HWOCR_EPI_LINEAR, st, q1));
     CHECK(hwocr_vit_rope_split(ws->qkv, ws->q, ws->k, ws->vt, lay->pos_h, lay->pos_w, m->rope_cos, m->rope_sin, rows,
                                rows, m->heads, hd, st));
     if (v25 && b.windowed && lay->nwin > 0) {
@@ -112,13 +122,13 @@ extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, con
     }
     CHECK(wide(ws->attn, b.proj_w, b.proj8, ws->q8, ws->q8s, b.proj_b, ws->x, ws->x, rows, D, DH, D, D, HWOCR_EPI_RESIDUAL,
                st));
-    CHECK(norm(b.ln2_w, b.ln2_b));
+    CHECK(q2 ? norm8(b.ln2_w, b.ln2_b) : norm(b.ln2_w, b.ln2_b));
     if (v25) {  // down(silu(gate(x)) * up(x)), all three with bias (HF modeling_qwen2_5_vl.py:84-96)
       CHECK(wide(ws->xn, b.fc1_w, b.fc18, ws->q8, ws->q8s, b.fc1_b, nullptr, ws->mlp, rows, 2 * m->mlp_dim, D, m->mlp_dim, 0,
-                 HWOCR_EPI_SWIGLU, st));
+                 HWOCR_EPI_SWIGLU, st, q2));
     } else {
       CHECK(wide(ws->xn, b.fc1_w, b.fc18, ws->q8, ws->q8s, b.fc1_b, nullptr, ws->mlp, rows, m->mlp_dim, D, m->mlp_dim, 0,
-                 sig ? HWOCR_EPI_GELU_TANH : HWOCR_EPI_QUICKGELU, st));
+                 sig ? HWOCR_EPI_GELU_TANH : HWOCR_EPI_QUICKGELU, st, q2));
     }
     CHECK(wide(ws->mlp, b.fc2_w, b.fc28, ws->q8, ws->q8s, b.fc2_b, ws->x, ws->x, rows, D, m->mlp_dim, D, D,
                HWOCR_EPI_RESIDUAL, st));
@@ -153,10 +163,14 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
     const hwocr_dec_layer& L = m->L[l];
     bf16* Kc = B(kv->k) + l * k_layer + seq0 * k_seq;
     bf16* Vc = B(kv->vt) + l * k_layer + seq0 * k_seq;
-    CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.in_norm_w, ws->hn, Hd, nullptr, rows, Hd, m->eps,
-                            G, st));
+    const bool q1 = runs_fp8(L.qkv8, ws->q8, ws->q8s, Hd), q2 = runs_fp8(L.gate_up8, ws->q8, ws->q8s, Hd);
+    if (q1)
+      CHECK(hwocr_rmsnorm_fp8(ws->h, Hd, L.in_norm_w, ws->q8, ws->q8s, Hd, rows, Hd, m->eps, G, st));
+    else
+      CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.in_norm_w, ws->hn, Hd, nullptr, rows, Hd, m->eps,
+                              G, st));
     CHECK(wide(ws->hn, L.qkv_w, L.qkv8, ws->q8, ws->q8s, L.qkv_b, nullptr, ws->qkv, rows, QW, Hd, QW, 0, HWOCR_EPI_LINEAR,
-               st));
+               st, q1));
     CHECK(hwocr_mrope_kv_prefill(ws->qkv, ws->q, Kc, Vc, pos3, m->rope_cos, m->rope_sin, rows, rows_per_seq, m->Hq,
                                  m->Hkv, m->sec0, m->sec1, k_seq, k_head, k_seq, k_head, kv->ctx, HD, kv->tiled, st));
     // Gemma (PaliGemma): the whole prompt is a bidirectional prefix; Qwen: causal
@@ -166,10 +180,13 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
                              (long)rows_per_seq * m->Hq * HD, (long)m->Hq * HD, scale, kv->tiled, st));
     CHECK(wide(ws->attn, L.o_w, L.o8, ws->q8, ws->q8s, nullptr, ws->h, ws->h, rows, Hd, m->Hq * HD, Hd, Hd,
                HWOCR_EPI_RESIDUAL, st));
-    CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd, nullptr, rows, Hd,
-                            m->eps, G, st));
+    if (q2)
+      CHECK(hwocr_rmsnorm_fp8(ws->h, Hd, L.post_norm_w, ws->q8, ws->q8s, Hd, rows, Hd, m->eps, G, st));
+    else
+      CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd, nullptr, rows, Hd,
+                              m->eps, G, st));
     CHECK(wide(ws->hn, L.gate_up_w, L.gate_up8, ws->q8, ws->q8s, nullptr, nullptr, ws->act, rows, 2 * m->inter, Hd, m->inter,
-               0, G ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, st));
+               0, G ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, st, q2));
     CHECK(wide(ws->act, L.down_w, L.down8, ws->q8, ws->q8s, nullptr, ws->h, ws->h, rows, Hd, m->inter, Hd, Hd,
                HWOCR_EPI_RESIDUAL, st));
   }

@@ -55,6 +55,12 @@ int hwocr_gemm_wide(const void* X, const void* W, const void* bias, const void* 
  * hwocr_gemm_wide_fp8: out = epi(xscale[m] * wscale[n] * sum_k X8[m][k] W8[n][k]) on v_mfma_f32_16x16x128_f8f6f4 with fp32
  * accumulation; bias / res / out stay bf16 and the epilogues are those of hwocr_gemm_wide.  K % 128 == 0, N % 8 == 0. */
 int hwocr_quant_rows_fp8(const void* X, void* Q, float* scale, int rows, int K, int ldx, int ldq, hwocr_stream_t stream);
+/* hwocr_layernorm / hwocr_add_rmsnorm (no slabs, no gather) that hand their bf16 result straight to hwocr_quant_rows_fp8
+ * inside the kernel: same codes and scales as the two calls, the bf16 row never goes to HBM */
+int hwocr_layernorm_fp8(const void* x, const void* w, const void* b, void* q8, float* q8s, int rows, int D, int ldx, int ldq,
+                        float eps, hwocr_stream_t stream);
+int hwocr_rmsnorm_fp8(const void* h, int ldh, const void* w, void* q8, float* q8s, int ldq, int rows, int D, float eps,
+                      int gemma, hwocr_stream_t stream);
 int hwocr_gemm_wide_fp8(const void* X8, const float* xscale, const void* W8, const float* wscale, const void* bias,
                         const void* res, void* out, int M, int N, int K, int ldx, int ldw, int ldo, int ldres, int epi,
                         hwocr_stream_t stream);

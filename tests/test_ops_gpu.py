@@ -651,3 +651,25 @@ def test_gemm_wide_fp8_rejects_bad_shapes():
     assert lib().hwocr_gemm_wide_fp8(p(z), p(s), p(z), p(s), None, None, p(o), 256, 256, 192, 256, 256, 256, 0, 0, st()) == 1
     assert lib().hwocr_gemm_wide_fp8(p(z), None, p(z), p(s), None, None, p(o), 256, 256, 256, 256, 256, 256, 0, 0, st()) == 1
     assert lib().hwocr_quant_rows_fp8(p(o), p(z), p(s), 256, 100, 256, 256, st()) == 1
+
+
+@pytest.mark.parametrize("rows,D", [(5, 128), (1000, 1152), (33, 2048), (130, 3584)])
+def test_norms_emitting_fp8_equal_norm_then_quantise(rows, D):
+    """hwocr_layernorm_fp8 / hwocr_rmsnorm_fp8 = the bf16 norm followed by hwocr_quant_rows_fp8, bit for bit."""
+    x = randbf(rows, D, scale=1.5, seed=31)
+    w = randbf(D, scale=0.3, seed=32) + 1.0
+    b = randbf(D, scale=0.2, seed=33)
+    xn = torch.empty(rows, D, dtype=torch.bfloat16, device=DEV)
+    for kind in ("layernorm", "rms", "rms_gemma"):
+        q = torch.full((rows, D), 0x7F, dtype=torch.uint8, device=DEV)
+        s = torch.full((rows,), float("nan"), dtype=torch.float32, device=DEV)
+        if kind == "layernorm":
+            assert lib().hwocr_layernorm(p(x), p(w), p(b), p(xn), rows, D, D, D, 1e-6, st()) == 0
+            assert lib().hwocr_layernorm_fp8(p(x), p(w), p(b), p(q), p(s), rows, D, D, D, 1e-6, st()) == 0
+        else:
+            g = 1 if kind == "rms_gemma" else 0
+            assert lib().hwocr_add_rmsnorm(None, 0, 0, 0, None, p(x), D, p(w), p(xn), D, None, rows, D, 1e-6, g, st()) == 0
+            assert lib().hwocr_rmsnorm_fp8(p(x), D, p(w), p(q), p(s), D, rows, D, 1e-6, g, st()) == 0
+        sync()
+        q2, s2 = _quant_gpu(xn)
+        assert torch.equal(q, q2) and torch.equal(s, s2), kind
