@@ -229,6 +229,222 @@ __global__ __launch_bounds__(256, HD > 128 ? 1 : 2) void attn_prefill_kernel(Pre
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gemma prefill specialisation: head_dim 256, non-causal (PaliGemma's bidirectional prefix), row-major K / V^T, MQA/GQA.
+// Same mathematics as attn_prefill_kernel<256,false>; what changes is how operands reach the matrix pipe:
+//   * K / V^T tiles staged by LDS-DMA (the generic kernel spends 128 VGPRs on global->register->LDS staging), so the
+//     query fragments (64 VGPRs) live in registers instead of being re-read from L2 every k-step;
+//   * WAVES x 32 queries per workgroup stream one K / V^T: 8 waves halve the bytes entering the CU per query;
+//   * swizzled LDS images (permutation applied to the DMA SOURCE address):
+//       K   : [64 keys][512 B], 16-byte chunk p of row r holds chunk p ^ (r & 15)
+//       V^T : [256 d  ][128 B], chunk p of row d holds chunk p ^ ((d >> 1) & 7)
+//   * 1-D grid dealt so that every XCD owns whole reads: all query blocks and all query heads that share one read's
+//     K / V^T (8.4 MB at 4113 tokens) share one L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int G256_K = 64 * 512, G256_VT = 256 * 128, G256_STAGE = G256_K + G256_VT;  // 64 KiB per stage
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void attn_hd256_kernel(PrefillArgs a) {
+  constexpr int HD = 256, NT = 64 * WAVES, NS = 16, ND = 8;
+  constexpr int N_DMA = 64 / WAVES;  // 1-KiB DMA instructions per wave per tile: 32 for K (2 key rows each), 32 for V^T (8 d rows)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages
+  int seg, h, q0;
+  {
+    const int per_seg = a.heads * a.qblocks, L = blockIdx.x;  // qblocks: blocks of 32 * WAVES queries
+    int rem;
+    if ((a.nseg & 7) == 0) {
+      const int slot = L >> 3;
+      seg = (slot / per_seg) * 8 + (L & 7);
+      rem = slot % per_seg;
+    } else {
+      seg = L / per_seg;
+      rem = L % per_seg;
+    }
+    h = rem % a.heads;  // the heads of one query block run together: same K / V^T tiles, in step
+    q0 = (rem / a.heads) * (32 * WAVES);
+  }
+  const int len = a.lens[seg];
+  if (q0 >= len) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int hk = h / a.group;
+  const bf16* Qp = a.Q + seg * a.q_seg + h * a.q_head;
+  const bf16* Kp = a.K + seg * a.k_seg + hk * a.k_head;
+  const bf16* Vp = a.VT + seg * a.v_seg + hk * a.v_head;
+  const int qi = q0 + 32 * w + r;
+  const int rk = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);  // tile row -> key permutation (bits 2,3 swapped)
+
+  bf16x8 qf[NS];
+  {
+    const bf16* qrow = Qp + (long)min(qi, len - 1) * a.q_row + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *(const bf16x8*)(qrow + 16 * s);
+  }
+
+  const int nt = (len + 63) >> 6;
+  // DMA plan per tile: 64 instructions of 1 KiB, task k = w + WAVES e.  k < 32: K rows 2k, 2k+1; else V^T rows 8(k-32)..+7.
+  // The lane part of every source address is tile- and task-independent (two variants for K: the swizzle sees row & 15,
+  // and rows of successive tasks of a wave differ by 2 WAVES), the rest is wave-uniform.  K rows up to the end of the
+  // last 64-key tile are read unclamped (their scores are masked), like the V^T columns: the cache is 64-aligned.
+  const int krow = 2 * w + (lane >> 5);
+  const long kofs0 = (long)krow * a.k_row + (((lane & 31) ^ (krow & 15)) << 3);
+  const long kofs1 = (long)krow * a.k_row + (((lane & 31) ^ ((krow + 2 * WAVES) & 15)) << 3);
+  const int vd = 8 * w + (lane >> 3);
+  const long vofs = (long)vd * a.v_row + (((lane & 7) ^ ((vd >> 1) & 7)) << 3);
+  static_assert(WAVES == 4 || WAVES == 8, "task -> row arithmetic below assumes 2 WAVES | 16 and 8 WAVES | 64");
+  auto stage_tile = [&](int t) {
+    const int j0 = t * 64;
+    char* st = smem + (t & 1) * G256_STAGE;
+#pragma unroll
+    for (int e = 0; e < N_DMA / 2; ++e) {  // K: task w + WAVES e -> rows krow + 2 WAVES e
+      const bf16* src = Kp + (long)(j0 + 2 * WAVES * e) * a.k_row + ((e & 1) && WAVES == 4 ? kofs1 : kofs0);
+      __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR(st + (w + WAVES * e) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < N_DMA / 2; ++e) {  // V^T: task 32 + w + WAVES e -> d rows vd + 8 WAVES e (same swizzle: 8 WAVES e / 2 = 0 mod 8)
+      const bf16* src = Vp + (long)(8 * WAVES * e) * a.v_row + j0 + vofs;
+      __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR(st + G256_K + (w + WAVES * e) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 o[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  float m = NEG_BIG, l = 0.f;
+
+  stage_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int j0 = t * 64;
+    char* st = smem + (t & 1) * G256_STAGE;
+    if (t + 1 < nt) stage_tile(t + 1);  // into the stage tile t-1 occupied: every wave passed the barrier that ended it
+    if (j0 + 64 > len) {
+      // tail tile: keys past the read must contribute 0 * finite; their V^T columns are whatever the cache holds
+      for (int i = tid; i < HD * 64; i += NT) {
+        const int d = i >> 6, col = i & 63;
+        if (j0 + col >= len) {
+          const int ch = (col >> 3) ^ ((d >> 1) & 7);
+          ((bf16*)(st + G256_K + d * 128 + ch * 16))[col & 7] = (bf16)0.0f;
+        }
+      }
+      __syncthreads();
+    }
+    const char* kb = st;
+    const char* vb = st + G256_K;
+
+    // One wave per SIMD: nobody else hides the LDS latency, so a rolling window of fragments is kept 4 k-steps (8 MFMAs)
+    // ahead of the MFMA that consumes them; every slot is refilled right behind its use (sched_barrier pins the order).
+    auto k_frag = [&](int s, int half) {
+      const int row = 32 * half + rk;
+      return *(const bf16x8*)(kb + row * 512 + (((2 * s + hh) ^ (row & 15)) << 4));
+    };
+    auto v_frag = [&](int i) {  // i = 4 d + (2 kt + s2)
+      const int dr = (i >> 2) * 32 + r;
+      return *(const bf16x8*)(vb + dr * 128 + ((((i & 3) * 2 + hh) ^ ((dr >> 1) & 7)) << 4));
+    };
+    bf16x8 fr[8];
+    f32x16 s0, s1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fr[e] = k_frag(e >> 1, e & 1);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      __builtin_amdgcn_sched_barrier(0);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * (s & 3)], qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * (s & 3) + 1], qf[s], s1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 4 < NS) {
+        fr[2 * (s & 3)] = k_frag(s + 4, 0);
+        fr[2 * (s & 3) + 1] = k_frag(s + 4, 1);
+      } else {  // the first V^T fragments land under the softmax
+        fr[2 * (s & 3)] = v_frag(2 * (s & 3));
+        fr[2 * (s & 3) + 1] = v_frag(2 * (s & 3) + 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (j0 + 64 > len) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = j0 + 16 * (i >> 3) + 8 * hh + (i & 7);
+        if (key >= len) s0[i] = -INFINITY;
+        if (key + 32 >= len) s1[i] = -INFINITY;
+      }
+    }
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s0[i]), s1[i]);  // v_max3_f32
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;
+    if (__any(mx > m)) {
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+      m = m_new;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    }
+    float rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s0[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], a.scale_log2, -m));
+      s1[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], a.scale_log2, -m));
+      rs += s0[i] + s1[i];
+    }
+    l += rs;
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pb[0][s2][j] = f2bf(s0[8 * s2 + j]);
+        pb[1][s2][j] = f2bf(s1[8 * s2 + j]);
+      }
+    // O^T += V^T . P^T: fragment i = 4 d + (2 kt + s2), window of 8
+#pragma unroll
+    for (int i = 0; i < 4 * ND; ++i) {
+      __builtin_amdgcn_sched_barrier(0);
+      o[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 7], pb[(i >> 1) & 1][i & 1], o[i >> 2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 8 < 4 * ND) fr[i & 7] = v_frag(i + 8);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t+1 has had the whole multiply to land
+    __syncthreads();
+  }
+
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / l;
+  if (qi < len) {
+    bf16* orow = a.O + seg * a.o_seg + (long)qi * a.o_row + h * HD;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(o[d][4 * g + e] * inv);
+        *(bf16x4*)(orow + d * 32 + 8 * g + 4 * hh) = ov;
+      }
+  }
+}
+
+template <int WAVES>
+int launch_hd256(PrefillArgs a, int nseg, int heads, int max_len, hipStream_t st) {
+  static bool done = false;
+  if (!done) {
+    hipFuncSetAttribute((const void*)attn_hd256_kernel<WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G256_STAGE);
+    done = true;
+  }
+  a.qblocks = (max_len + 32 * WAVES - 1) / (32 * WAVES);
+  hipLaunchKernelGGL((attn_hd256_kernel<WAVES>), dim3(a.qblocks * heads * nseg), dim3(64 * WAVES), 2 * G256_STAGE, st, a);
+  return hwocr_launch_status();
+}
+
 template <int HD, bool CAUSAL>
 int launch_prefill(const PrefillArgs& a, int nseg, int heads, int max_len, hipStream_t st) {
   constexpr int HDP = (HD + 31) / 32 * 32;
@@ -679,6 +895,12 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
                                     : launch_prefill<80, false>(a, nseg, heads, max_len, stream);
   if (head_dim == 128) return causal ? launch_prefill<128, true>(a, nseg, heads, max_len, stream)
                                      : launch_prefill<128, false>(a, nseg, heads, max_len, stream);
+  if (head_dim == 256 && !causal && !kv_tiled) {
+    // HWOCR_HD256_WAVES=0: generic kernel.  (8 waves x 32 queries would halve the staged bytes per query but needs
+    // 256 + VGPRs per wave: hipcc spills 74 of them and the kernel measured no faster than the generic one.)
+    static const int waves = [] { const char* e = getenv("HWOCR_HD256_WAVES"); return e ? atoi(e) : 4; }();
+    if (waves == 4) return launch_hd256<4>(a, nseg, heads, max_len, stream);
+  }
   if (head_dim == 256) return causal ? launch_prefill<256, true>(a, nseg, heads, max_len, stream)
                                      : launch_prefill<256, false>(a, nseg, heads, max_len, stream);
   if (head_dim == 64) return causal ? launch_prefill<64, true>(a, nseg, heads, max_len, stream)

@@ -653,7 +653,8 @@ def test_gemm_wide_fp8_rejects_bad_shapes():
     assert lib().hwocr_quant_rows_fp8(p(o), p(z), p(s), 256, 100, 256, 256, st()) == 1
 
 
-@pytest.mark.parametrize("rows,D", [(5, 128), (1000, 1152), (33, 2048), (130, 3584)])
+# > 512 rows: hwocr_add_rmsnorm then runs the same wave-per-row kernel as the fp8 form (the few-row kernel sums in another order)
+@pytest.mark.parametrize("rows,D", [(600, 128), (1000, 1152), (700, 2048), (520, 3584)])
 def test_norms_emitting_fp8_equal_norm_then_quantise(rows, D):
     """hwocr_layernorm_fp8 / hwocr_rmsnorm_fp8 = the bf16 norm followed by hwocr_quant_rows_fp8, bit for bit."""
     x = randbf(rows, D, scale=1.5, seed=31)
@@ -673,3 +674,28 @@ def test_norms_emitting_fp8_equal_norm_then_quantise(rows, D):
         sync()
         q2, s2 = _quant_gpu(xn)
         assert torch.equal(q, q2) and torch.equal(s, s2), kind
+
+
+def test_attn_prefill_hd256_long_reads():
+    """The Gemma-prefill kernel at 8 reads (XCD-dealt grid), 8 query heads on one KV head, several K/V tiles and a ragged tail."""
+    hd, Hq, lens = 256, 8, [700, 513, 64, 1, 640, 333, 65, 128]
+    nseg, Lp = len(lens), 704
+    q = randbf(nseg, Lp, Hq, hd, seed=41)
+    k = randbf(nseg, 1, Lp, hd, seed=42)
+    v = randbf(nseg, 1, Lp, hd, seed=43)
+    vt = v.transpose(2, 3).contiguous()
+    for s, n in enumerate(lens):
+        vt[s, :, :, n:] = float("nan")
+        k[s, :, n:, :] = 1e4
+    out = torch.zeros(nseg, Lp, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    scale = hd ** -0.5
+    rc = lib().hwocr_attn_prefill(p(q), p(k), p(vt), p(out), p(lens_d), nseg, Hq, Hq, hd, max(lens), 0,
+                                  Lp * Hq * hd, hd, Hq * hd, Lp * hd, Lp * hd, hd, hd * Lp, hd * Lp, Lp, Lp * Hq * hd, Hq * hd,
+                                  scale, 0, st())
+    assert rc == 0
+    sync()
+    for s, n in enumerate(lens):
+        want = _sdpa_ref(q[s, :n].float().permute(1, 0, 2), k[s, :, :n].float(), v[s, :, :n].float(), False, scale)
+        assert_close_bf16(out[s, :n].view(n, Hq, hd), want, ulps=4.0, atol=4e-3, what=f"attn hd256 read {s}")
+    assert torch.isfinite(out.float()).all()
