@@ -7,8 +7,8 @@ third-party library transformers (reference pins 5.1.0, poetry.lock:5252-5253; v
 5.15.0); every function cites the HF file:line it follows (HF = site-packages/transformers/models).
 
 Pinned by tests/golden/paligemma_tiny_*.safetensors: outputs of the real HF classes on a seeded random-init model
-(vision head_dim 72 and decoder head_dim 256 like the 3B checkpoint), written by tools/make_goldens.py.  No product path
-exists for this family yet: the oracle and its goldens are what the next kernels will be checked against.
+(vision head_dim 72 and decoder head_dim 256 like the 3B checkpoint), written by tools/make_goldens.py; the product path
+(ReadEngine, family "paligemma") is checked against them in tests/test_model_paligemma_gpu.py.
 
 Only tests/ may import this module.
 """
