@@ -478,7 +478,7 @@ constexpr int V80_STAGE = V80_K0 + V80_K1 + V80_VT;  // 21504 B
 
 // WAVES x 32 queries per workgroup.  Every workgroup streams the whole K / V^T of its (head, page) through LDS, so the
 // bytes entering the CUs per query fall with the queries per workgroup: at 4 waves (128 queries, 3 workgroups per CU) a
-// 12-page launch staged 13.5 GB in 1.8 ms = 7.5 TB/s - the chip's into-CU ceiling, not the matrix or vector pipes, was
+// 12-page launch staged 13.5 GB in 1.8 ms = 7.5 TB/s, much of it from beyond L2 - the staging, not the matrix or vector pipes, was
 // the bound.  12 waves (384 queries, one workgroup per CU, the same 3 waves per SIMD) stage a third of that.
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void attn_vit80_kernel(PrefillArgs a) {

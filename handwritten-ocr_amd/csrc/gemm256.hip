@@ -65,6 +65,14 @@ __device__ __forceinline__ void quadrant_mma(f32x4 (&acc)[4][8], const i32x4 (&w
   __builtin_amdgcn_s_setprio(0);
 }
 
+// ablation (tools/bench_gemm_ablate.py): fragments stay live without the matrix pipe
+__device__ __forceinline__ void keep_alive(f32x4 (&acc)[4][8], const i32x4 (&wf)[2][2][2], const i32x4 (&xf)[4][2]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(xf[i][0]), "v"(xf[i][1]));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(wf[i][0][0]), "v"(wf[i][0][1]), "v"(wf[i][1][0]), "v"(wf[i][1][1]));
+}
+
 __device__ __forceinline__ void wait_units_in_flight(int units) {  // 2 DMA instructions per unit per thread
   switch (units) {
     case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
@@ -79,7 +87,7 @@ __device__ __forceinline__ void wait_units_in_flight(int units) {  // 2 DMA inst
 // its two waves ready.  Costs a second barrier per phase; LDS hazards hold because every unit is overwritten 7 phases
 // (14 segments) after... see the window derivation in DESIGN.md: last read of the old occupant at segment 2P-15, first
 // DMA of the new one at 2P-14; the retiring wait of the late half moves from after its multiply to after its load segment.
-template <int EPI, bool STAGGER, bool FP8>
+template <int EPI, bool STAGGER, bool FP8, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   constexpr int ES = FP8 ? 1 : 2;  // bytes per operand element; a K tile is 128 bytes of every row either way
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   const int nk = a.K * ES / 128;
   auto issue = [&](auto kind, int t) {  // unit (t, kind): 2 LDS-DMA instructions per thread
     constexpr int k = decltype(kind)::value;
-    if (t < nk) {
+    if (t < nk && (ABL == 0 || ABL == 2 || t < 2)) {
       char* st = smem + (t & 1) * STAGE + ((k == 1 || k == 2) ? TILE : 0) + ubase[k] * 128;
       __builtin_amdgcn_global_load_lds((const void*)(usrc[k][0] + t * 128), LDS_PTR(st), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const void*)(usrc[k][1] + t * 128), LDS_PTR(st + 128 * 128), 16, 0, 0);
@@ -134,7 +142,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   const int xrow0 = (128 * wr + c) * 128;          // + (64 mh + 16 i) * 128
   const int wrow0 = TILE + (64 * wc + c) * 128;    // + (32 nh + 16 j) * 128
   i32x4 xf[4][2], wf[2][2][2];
+  if constexpr (ABL == 4) {  // no LDS reads: the multiplies run on whatever the registers hold
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xf[i][0] = xf[i][1] = i32x4{tid, i, tid, i};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wf[i][0][0] = wf[i][0][1] = wf[i][1][0] = wf[i][1][1] = i32x4{i, tid, i, tid};
+  }
   auto read_x = [&](const char* st, int mh) {
+    if constexpr (ABL == 4) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -142,6 +157,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
         xf[i][kk] = *(const i32x4*)(st + xrow0 + (64 * mh + 16 * i) * 128 + (((kk * 4 + q) ^ sw) << 4));
   };
   auto read_w = [&](const char* st, int nh, i32x4 (&dst)[2][2]) {
+    if constexpr (ABL == 4) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
         dst[j][kk] = *(const i32x4*)(st + wrow0 + (32 * nh + 16 * j) * 128 + (((kk * 4 + q) ^ sw) << 4));
   };
   auto phase_end = [&]() {
-    __builtin_amdgcn_s_barrier();
+    if constexpr (ABL != 3) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -167,21 +183,21 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
       read_x(st, 0);
       read_w(st, 0, wf[0]);
       issue(K3{}, t + 1);  // unit P + 7
-      quadrant_mma<FP8, 0, 0>(acc, wf, xf);
+      if constexpr (ABL != 2) quadrant_mma<FP8, 0, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
       phase_end();
       // ph1: (m0, n1)
       read_w(st, 1, wf[1]);
       issue(K0{}, t + 2);
-      quadrant_mma<FP8, 0, 1>(acc, wf, xf);
+      if constexpr (ABL != 2) quadrant_mma<FP8, 0, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
       phase_end();
       // ph2: (m1, n1)
       read_x(st, 1);
       issue(K1{}, t + 2);
-      quadrant_mma<FP8, 1, 1>(acc, wf, xf);
+      if constexpr (ABL != 2) quadrant_mma<FP8, 1, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
       phase_end();
       // ph3: (m1, n0); retire K tile t+1, keep the units issued behind it in flight
       issue(K2{}, t + 2);
-      quadrant_mma<FP8, 1, 0>(acc, wf, xf);
+      if constexpr (ABL != 2) quadrant_mma<FP8, 1, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
       wait_units_in_flight(max(0, min(3, total_units - 1 - (P + 7))));
       phase_end();
     }
@@ -195,22 +211,22 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
       read_w(st, 0, wf[0]);
       issue(K3{}, t + 1);
       phase_end();
-      quadrant_mma<FP8, 0, 0>(acc, wf, xf);
+      if constexpr (ABL != 2) quadrant_mma<FP8, 0, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
       phase_end();
       read_w(st, 1, wf[1]);
       issue(K0{}, t + 2);
       phase_end();
-      quadrant_mma<FP8, 0, 1>(acc, wf, xf);
+      if constexpr (ABL != 2) quadrant_mma<FP8, 0, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
       phase_end();
       read_x(st, 1);
       issue(K1{}, t + 2);
       phase_end();
-      quadrant_mma<FP8, 1, 1>(acc, wf, xf);
+      if constexpr (ABL != 2) quadrant_mma<FP8, 1, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
       phase_end();
       issue(K2{}, t + 2);
       if (late) wait_units_in_flight(keep);
       phase_end();
-      quadrant_mma<FP8, 1, 0>(acc, wf, xf);
+      if constexpr (ABL != 2) quadrant_mma<FP8, 1, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
       if (!late) wait_units_in_flight(keep);
       phase_end();
     }
@@ -304,6 +320,18 @@ void launch(const WideArgs& a, hipStream_t st) {
   WideArgs b = a;
   b.tilesM = (a.M + BM - 1) / BM;
   b.tilesN = (a.N + BN - 1) / BN;
+  if constexpr (EPI == EPI_LINEAR && !FP8) {  // measurement only: wrong results by construction
+    static const int ablate = [] { const char* e = getenv("HWOCR_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    if (ablate >= 1 && ablate <= 4) {
+      auto k = ablate == 1 ? gemm_wide256_kernel<EPI_LINEAR, true, false, 1>
+               : ablate == 2 ? gemm_wide256_kernel<EPI_LINEAR, true, false, 2>
+               : ablate == 3 ? gemm_wide256_kernel<EPI_LINEAR, true, false, 3>
+                             : gemm_wide256_kernel<EPI_LINEAR, true, false, 4>;
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipLaunchKernelGGL(k, dim3(b.tilesM * b.tilesN), dim3(512), LDS_BYTES, st, b);
+      return;
+    }
+  }
   if (variant == 1) launch_one<EPI, false, FP8>(b, st);
   else launch_one<EPI, true, FP8>(b, st);
 }

@@ -23,8 +23,8 @@
 // global_load + ds_write.  Measured on the way: 4 waves 2.9 TB/s of weights, 8 waves 4.0, 16 waves 4.4-4.5 (16 rows
 // instead of 126, i.e. an 8x smaller x tile: 5.6 TB/s); time = (W + 256 x-tiles) / 8 TB/s within 5 % on every shape.
 // A variant with the weights HBM -> VGPR in a 4-deep hand-unrolled register ring (exact compiler vmcnt waits once the
-// loop has no separate prologue and no load under a t-dependent branch) and x by plain loads + ds_write ran at the same
-// bytes-into-CU ceiling but re-read weight tiles for idle waves: 3.3 TB/s; dropped.
+// loop has no separate prologue and no load under a t-dependent branch) and x by plain loads + ds_write moved bytes into
+// the CUs at the same rate but re-read weight tiles for idle waves: 3.3 TB/s; dropped.
 // Epilogues as gemm_skinny: PARTIAL fp32 split-K slabs, LINEAR (+bias), SWIGLU / GEGLU on interleaved gate/up tile pairs.
 #include "gemm_common.cuh"
 #include <cstdlib>
