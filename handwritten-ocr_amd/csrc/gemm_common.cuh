@@ -117,3 +117,5 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream);
 // launcher of the 256x256 kernel (gemm256.hip); returns HWOCR_EINVAL when the shape does not qualify
 int hwocr_gemm_wide256(const gemm::WideArgs& a, int epi, hipStream_t stream);
 int hwocr_gemm_wide256_fp8(const gemm::WideArgs& a, int epi, hipStream_t stream);
+// the four-wave structure of the same tile (gemm256x4.hip)
+int hwocr_gemm_wide256x4(const gemm::WideArgs& a, int epi, hipStream_t stream);
