@@ -385,8 +385,8 @@ def main() -> None:
     mfma_peak = FP8_MFMA_PEAK_TFLOPS if args.fp8 else BF16_MFMA_PEAK_TFLOPS
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f)["kernels"]["gemm_wide256_kernel"]["traffic_bytes"]
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_fp8.json" if args.fp8 else "pmc_traffic.json")) as f:
+            traffic = json.load(f)["kernels"]["gemm_wide256_kernel_fp8" if args.fp8 else "gemm_wide256_kernel"]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         pass
     out = {
@@ -403,8 +403,8 @@ def main() -> None:
                      "kernel": ("gemm_wide256_kernel<FP8> (E4M3 256x256x128 MFMA GEMM on v_mfma_f32_16x16x128_f8f6f4, 8 waves, staggered phases)"
                                 if args.fp8 else "gemm_wide256_kernel (bf16 256x256x64 MFMA GEMM, 8 waves, staggered phases)"),
                      "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s",
-                     "frac": achieved / mfma_peak, "traffic": None if args.fp8 else traffic,
-                     "traffic_note": "bytes per launch from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)",
+                     "frac": achieved / mfma_peak, "traffic": traffic,
+                     "traffic_note": "bytes per launch from profiles/pmc_traffic%s.json (separate rocprofv3 --pmc passes)" % ("_fp8" if args.fp8 else ""),
                      "launches": int(n.value), "avg_launch_ms": ms.value / max(1, n.value),
                      "algorithmic_flops_per_launch": fl.value / max(1, n.value),
                      "share_of_step_time": ms.value / (elapsed * 1e3)},
