@@ -342,9 +342,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attn_hd256_kernel(PrefillArgs a
       const int row = 32 * half + rk;
       return *(const bf16x8*)(kb + row * 512 + (((2 * s + hh) ^ (row & 15)) << 4));
     };
-    auto v_frag = [&](int i) {  // i = 4 d + (2 kt + s2)
-      const int dr = (i >> 2) * 32 + r;
-      return *(const bf16x8*)(vb + dr * 128 + ((((i & 3) * 2 + hh) ^ ((dr >> 1) & 7)) << 4));
+    auto v_frag = [&](int i) {  // i = 8 (2 kt + s2) + d: consecutive MFMAs of the PV product go to DIFFERENT accumulators
+      const int dr = (i & 7) * 32 + r;
+      return *(const bf16x8*)(vb + dr * 128 + ((((i >> 3) * 2 + hh) ^ ((dr >> 1) & 7)) << 4));
     };
     bf16x8 fr[8];
     f32x16 s0, s1;
@@ -405,11 +405,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attn_hd256_kernel(PrefillArgs a
         pb[0][s2][j] = f2bf(s0[8 * s2 + j]);
         pb[1][s2][j] = f2bf(s1[8 * s2 + j]);
       }
-    // O^T += V^T . P^T: fragment i = 4 d + (2 kt + s2), window of 8
+    // O^T += V^T . P^T: fragment i = 8 (2 kt + s2) + d, window of 8
 #pragma unroll
     for (int i = 0; i < 4 * ND; ++i) {
       __builtin_amdgcn_sched_barrier(0);
-      o[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 7], pb[(i >> 1) & 1][i & 1], o[i >> 2], 0, 0, 0);
+      o[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 7], pb[i >> 4][(i >> 3) & 1], o[i & 7], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (i + 8 < 4 * ND) fr[i & 7] = v_frag(i + 8);
     }
@@ -897,7 +897,9 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
                                      : launch_prefill<128, false>(a, nseg, heads, max_len, stream);
   if (head_dim == 256 && !causal && !kv_tiled) {
     // HWOCR_HD256_WAVES=0: generic kernel.  (8 waves x 32 queries would halve the staged bytes per query but needs
-    // 256 + VGPRs per wave: hipcc spills 74 of them and the kernel measured no faster than the generic one.)
+    // 256 + VGPRs per wave: hipcc spills 74 of them and the kernel measured no faster than the generic one.  32-key tiles
+    // in four LDS stages - three tiles in flight instead of one - measured 4.1-4.3 ms at 4 waves and 3.6-4.2 ms at 8 (21-35
+    // spills) against 3.47 ms: the time is not DMA latency.)
     static const int waves = [] { const char* e = getenv("HWOCR_HD256_WAVES"); return e ? atoi(e) : 4; }();
     if (waves == 4) return launch_hd256<4>(a, nseg, heads, max_len, stream);
   }
