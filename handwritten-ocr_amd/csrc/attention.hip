@@ -30,6 +30,10 @@ struct PrefillArgs {
   int kv_tiled;       // K / V^T in the fragment-tiled cache layout (common.cuh) instead of rows
   int heads, nseg, qblocks;  // 1-D grid decomposition (attn_vit80_kernel)
   const int* seg_off;        // packed ragged segments (hwocr_attn_varlen): first row of every segment, multiple of 4
+  // Lazy running-max update of the two specialised kernels: the accumulators are rescaled only when some query's tile maximum
+  // exceeds its running reference by more than `slack` (log2 units); until then the weights are exp2(s - m_ref) <= 2^slack
+  // - still exact relative precision in bf16 / fp32 - and O / l is unchanged.  0 = rescale on every new maximum.
+  float slack = 0.f;
 };
 
 __device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attn_hd256_kernel(PrefillArgs a
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s0[i]), s1[i]);  // v_max3_f32
     mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;
-    if (__any(mx > m)) {
+    if (__any(mx > m + a.slack)) {
       const float m_new = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f(m - m_new);
       l *= alpha;
@@ -433,6 +437,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attn_hd256_kernel(PrefillArgs a
   }
 }
 
+// HWOCR_ATTN_SLACK: log2 slack of the lazy running-max update (default 8: weights up to 256; 0 = exact schedule)
+inline float attn_slack() {
+  static const float v = [] { const char* e = getenv("HWOCR_ATTN_SLACK"); return e ? (float)atof(e) : 8.0f; }();
+  return v;
+}
+
 template <int WAVES>
 int launch_hd256(PrefillArgs a, int nseg, int heads, int max_len, hipStream_t st) {
   static bool done = false;
@@ -441,6 +451,7 @@ int launch_hd256(PrefillArgs a, int nseg, int heads, int max_len, hipStream_t st
     done = true;
   }
   a.qblocks = (max_len + 32 * WAVES - 1) / (32 * WAVES);
+  a.slack = attn_slack();
   hipLaunchKernelGGL((attn_hd256_kernel<WAVES>), dim3(a.qblocks * heads * nseg), dim3(64 * WAVES), 2 * G256_STAGE, st, a);
   return hwocr_launch_status();
 }
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void attn_vit80_ker
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s0[i]), s1[i]);  // v_max3_f32
     mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;
-    if (__any(mx > m)) {
+    if (__any(mx > m + a.slack)) {
       const float m_new = fmaxf(m, mx);
       const float alpha = __builtin_amdgcn_exp2f(m - m_new);
       m = m_new;
@@ -686,6 +697,7 @@ int launch_vit80(const PrefillArgs& a, int nseg, int heads, int max_len, hipStre
   b.heads = heads;
   b.nseg = nseg;
   b.qblocks = (max_len + 32 * waves - 1) / (32 * waves);
+  b.slack = attn_slack();
   if (waves == 12) {
     static bool done = false;
     if (!done) {
