@@ -1,6 +1,8 @@
 """Where the 256x256 GEMM's time goes: the product kernel against two ablations of itself (HWOCR_GEMM_ABLATE=1: no LDS-DMA after
-the prologue — matrix pipe + LDS reads + barriers only; =2: no MFMA — staging + LDS reads + barriers only).  Run on the GPU box
-once per setting: HWOCR_GEMM_ABLATE=<0|1|2> python tools/bench_gemm_ablate.py"""
+the prologue — matrix pipe + LDS reads + barriers only; =2: no MFMA — staging + LDS reads + barriers only; =3: 1 without barriers;
+=4: 1 without fragment reads; =5: the whole main loop, no epilogue; =6: everything but the epilogue's global stores; =7 / 8 / 9: the epilogue's stores
+non-temporal / sc1 / sc0 sc1 instead of the default policy).  Run on the GPU box once per setting:
+HWOCR_GEMM_ABLATE=<0..9> python tools/bench_gemm_ablate.py"""
 import os
 import sys
 
@@ -11,7 +13,7 @@ sys.path.insert(0, ROOT)
 from handwritten_ocr_amd import _lib  # noqa: E402
 
 lib, p = _lib.hip(), _lib.ptr
-for M, N, K in ((62208, 5120, 1280), (62208, 1280, 5120), (21248, 17920, 1536), (16384, 8192, 8192)):
+for M, N, K in ((62208, 5120, 1280), (62208, 1280, 5120), (62208, 5120, 128), (21248, 17920, 1536), (16384, 8192, 8192)):
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
