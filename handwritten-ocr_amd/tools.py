@@ -57,7 +57,8 @@ def _load_ocr_model():
         tok = tokenizer.ByteTokenizer(cfg, fold_unknown=True)
     cfg.min_pixels, cfg.max_pixels = config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS
     _ocr_model = engine.ReadEngine(cfg, sd, max_reads=int(os.environ.get("HWOCR_MAX_READS", "252")),
-                                   ctx=int(os.environ.get("HWOCR_CTX", "4096")))
+                                   ctx=int(os.environ.get("HWOCR_CTX", "4096")),
+                                   fp8=os.environ.get("HWOCR_FP8", "0") not in ("", "0"))
     _ocr_processor = tokenizer.Processor(cfg, tok)
     print("  [ocr] Model loaded.")
     return _ocr_model, _ocr_processor
