@@ -125,6 +125,11 @@ _HIP_SIGS = {
                                    C.POINTER(P)], I),
     "hwocr_decode_graph_launch": ([P, I, P], I),
     "hwocr_decode_graph_destroy": ([P], I),
+    "hwocr_img_luma_sum": ([P, L, P, P], I),
+    "hwocr_img_contrast": ([P, P, L, I, F, P], I),
+    "hwocr_img_binarize": ([P, P, L, P], I),
+    "hwocr_img_sharpen": ([P, P, I, I, P], I),
+    "hwocr_img_resize_bicubic": ([P, P, P, I, I, I, I, P, P, I, P, P, I, P], I),
     "hwocr_profile_enable": ([I], I),
     "hwocr_profile_read": ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)], I),
 }

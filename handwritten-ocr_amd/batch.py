@@ -27,9 +27,12 @@ import argparse
 import contextlib
 import io
 import json
+import os
 import sys
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
+
+import numpy as np
 
 from PIL import Image
 
@@ -91,13 +94,30 @@ def initial_ocr_batched(image_paths: list, params: dict | None = None, cfg=confi
     (strategies, texts) of everything that was read."""
     strategies = _speculative_strategies(list(cfg.PREPROCESSING_STRATEGIES), every=speculate_reocr)
 
+    # HWOCR_GPU_PREPROCESS=1 (SURVEY 8f-3): the strategy chains and the processor's resize run on the device, bit-identical
+    # to the host path (gpupre.py); a page is decoded and uploaded once for all its reads.  Pages that are not plain RGB and
+    # chains the device path does not cover (OpenCV present, a transform after binarize) keep the host path.
+    gpu_pages = None
+    if os.environ.get("HWOCR_GPU_PREPROCESS", "0") not in ("", "0"):
+        from . import gpupre
+
+        if all(gpupre.supported(s) for s in strategies):
+            model, processor = tools._load_ocr_model()
+            gpu_pages = (gpupre.StrategyPages(model.dev), processor)
+
     def prepare(path):
         img = Image.open(path)
         img.load()
+        if gpu_pages is not None and img.mode == "RGB":
+            return np.asarray(img)
         return [preprocess.apply_strategy(img, s, quiet=True) for s in strategies]
 
     with ThreadPoolExecutor(max_workers=workers) as pool:
         prepared = list(pool.map(prepare, image_paths))
+    if gpu_pages is not None:
+        sp, processor = gpu_pages
+        prepared = [sp.pages(p, strategies, processor.target_hw(p.shape[0], p.shape[1])) if isinstance(p, np.ndarray) else p
+                    for p in prepared]
     flat = [im for page in prepared for im in page]
     texts = tools.run_ocr_batch(flat, params)
     states = []

@@ -61,6 +61,15 @@ class Processor:
         self.cfg = cfg
         self.tokenizer = tokenizer
 
+    def target_hw(self, height: int, width: int) -> tuple[int, int]:
+        """Resolution `prepare` resizes a page of this size to (what the device preprocessing must produce)."""
+        from . import imageproc
+
+        c = self.cfg
+        if c.family == "paligemma":
+            return c.image_size, c.image_size
+        return imageproc.smart_resize(height, width, c.patch_size * c.merge, c.min_pixels, c.max_pixels)
+
     def image_tokens(self, page: np.ndarray) -> int:
         c = self.cfg
         return (page.shape[0] // c.patch_size) * (page.shape[1] // c.patch_size) // c.merge ** 2

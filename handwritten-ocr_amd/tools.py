@@ -78,7 +78,8 @@ def unload_ocr_model():
 
 
 def run_ocr_batch(images: list, params: dict | None = None) -> list[str]:
-    """Read many (already preprocessed) pages in one engine batch.  `images`: paths or PIL images."""
+    """Read many (already preprocessed) pages in one engine batch.  `images`: paths, PIL images, or uint8 [H][W][3] device
+    tensors already at the tower's resolution (gpupre.StrategyPages)."""
     params = params or {}
     model, processor = _load_ocr_model()
     prompt = params.get("prompt", config.OCR_PROMPT)
@@ -86,6 +87,10 @@ def run_ocr_batch(images: list, params: dict | None = None) -> list[str]:
     min_new = params.get("min_new_tokens", 0)
     pages, prompts = [], []
     for im in images:
+        if hasattr(im, "data_ptr"):  # torch tensor resident in HBM
+            pages.append(im)
+            prompts.append(processor.chat_ids(prompt, processor.image_tokens(im)))
+            continue
         img = im if isinstance(im, Image.Image) else Image.open(im)
         page, ids = processor.prepare(img, prompt)
         pages.append(page)

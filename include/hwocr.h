@@ -247,6 +247,18 @@ int hwocr_decode_graph_create(const hwocr_decoder* m, const hwocr_dec_ws* ws, co
 int hwocr_decode_graph_launch(void* graph, int n, hwocr_stream_t stream);
 int hwocr_decode_graph_destroy(void* graph);
 
+/* ---- strategy preprocessing on the device (csrc/imagepre.hip): the reference's transforms in their PIL-fallback form
+ * (ocr_agent/tools.py:514-516 high_contrast, :530-531 binarize, :544-546 sharpen) and the image processor's bicubic resize
+ * (HF image_processing_pil_qwen2_vl.py:152-183 -> Pillow Resample.c), bit-identical to Pillow.  Images: uint8 [H][W][3]. */
+int hwocr_img_luma_sum(const void* rgb, long npix, unsigned long long* sum, hwocr_stream_t stream); /* sum of convert("L") */
+int hwocr_img_contrast(const void* src, void* dst, long nbytes, int mean, float factor, hwocr_stream_t stream);
+int hwocr_img_binarize(const void* rgb, void* dst_rgb, long npix, hwocr_stream_t stream);
+int hwocr_img_sharpen(const void* src, void* dst, int H, int W, hwocr_stream_t stream); /* src != dst */
+/* tmp: H * out_w * 3 bytes; bounds [n_out][2] = (first tap, taps), coef [n_out][ksize] = Pillow's 22-bit fixed-point taps */
+int hwocr_img_resize_bicubic(const void* src, void* tmp, void* dst, int H, int W, int out_h, int out_w, const int* h_bounds,
+                             const int* h_coef, int h_ksize, const int* v_bounds, const int* v_coef, int v_ksize,
+                             hwocr_stream_t stream);
+
 /* bench instrumentation: HIP events on the launch stream around every hwocr_gemm_wide (on == 1) or hwocr_gemm_wide_fp8
  * (on == 2) launch while enabled */
 int hwocr_profile_enable(int on);

@@ -28,7 +28,7 @@ def test_binding_table_matches_header():
 
 
 def test_abi_version_and_structs():
-    assert _lib.hip().hwocr_abi_version() == 5
+    assert _lib.hip().hwocr_abi_version() == 6
     # layout contract with include/hwocr.h (LP64): ints, one float, then 8-byte-aligned pointers
     assert C.sizeof(_lib.Vit) == 48 + 13 * 8 and C.sizeof(_lib.VitBlock) == 21 * 8 and C.sizeof(_lib.VitLayout) == 7 * 8 and C.sizeof(_lib.Decoder) == 48 + 7 * 8 and C.sizeof(_lib.DecLayer) == 19 * 8
     assert C.sizeof(_lib.GenState) == 6 * 8 + 8 * 4 + 8 + 2 * 4 and C.sizeof(_lib.Kv) == 32
