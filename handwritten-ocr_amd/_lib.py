@@ -10,6 +10,8 @@ import os
 
 from . import build as _build
 
+ABI_VERSION = 6  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
+
 P = C.c_void_p
 I = C.c_int
 L = C.c_long
@@ -168,7 +170,11 @@ def hip() -> C.CDLL:
             raise HwocrError(
                 f"{_build.HIP_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
                 "the page-read engine has no CPU fallback")
-        _hip = _bind(_build.HIP_LIB, _HIP_SIGS)
+        lib = _bind(_build.HIP_LIB, _HIP_SIGS)
+        if lib.hwocr_abi_version() != ABI_VERSION:  # a stale build: struct layouts would not match
+            raise HwocrError(f"{_build.HIP_LIB} reports ABI {lib.hwocr_abi_version()}, these bindings are for {ABI_VERSION}: "
+                             "rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
+        _hip = lib
     return _hip
 
 

@@ -59,7 +59,7 @@ inline int wide(const void* X, const void* W, const hwocr_w8& w8, void* q8, floa
 }
 }  // namespace
 
-extern "C" int hwocr_abi_version(void) { return 6; }
+extern "C" int hwocr_abi_version(void) { return HWOCR_ABI_VERSION; }
 
 static char g_last_error[256] = "";
 extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text) {

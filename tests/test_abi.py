@@ -28,7 +28,11 @@ def test_binding_table_matches_header():
 
 
 def test_abi_version_and_structs():
-    assert _lib.hip().hwocr_abi_version() == 6
+    import re
+
+    with open(os.path.join(ROOT, "include", "hwocr.h")) as f:
+        declared = int(re.search(r"#define HWOCR_ABI_VERSION (\d+)", f.read()).group(1))
+    assert _lib.hip().hwocr_abi_version() == declared == _lib.ABI_VERSION
     # layout contract with include/hwocr.h (LP64): ints, one float, then 8-byte-aligned pointers
     assert C.sizeof(_lib.Vit) == 48 + 13 * 8 and C.sizeof(_lib.VitBlock) == 21 * 8 and C.sizeof(_lib.VitLayout) == 7 * 8 and C.sizeof(_lib.Decoder) == 48 + 7 * 8 and C.sizeof(_lib.DecLayer) == 19 * 8
     assert C.sizeof(_lib.GenState) == 6 * 8 + 8 * 4 + 8 + 2 * 4 and C.sizeof(_lib.Kv) == 32
