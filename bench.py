@@ -74,6 +74,30 @@ def build_inputs(cfg, n_pages: int, seed0: int, reads_per_page: int, side: int, 
     return pages, prompts, host_s
 
 
+def device_preprocess_probe(cfg, host_pages, seed0: int, reads_per_page: int, side: int, device, n_probe: int = 4):
+    """The same strategy reads of the first pages made on the device (gpupre.py): seconds per page, upload included, and
+    whether the tensors equal the host-made ones (they must).  None where the device path does not apply (OpenCV present)."""
+    from handwritten_ocr_amd import gpupre, imageproc, synth
+    from handwritten_ocr_amd.compat import config
+
+    strategies = config.PREPROCESSING_STRATEGIES[:reads_per_page]
+    if not all(gpupre.supported(s) for s in strategies):
+        return None
+    sp = gpupre.StrategyPages(device)
+    hw = ((cfg.image_size, cfg.image_size) if cfg.family == "paligemma" else
+          imageproc.smart_resize(side, side, cfg.patch_size * cfg.merge, config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS))
+    n_probe = min(n_probe, len(host_pages) // reads_per_page)
+    raws = [np.ascontiguousarray(synth.make_page(seed0 + p, side, side)) for p in range(n_probe)]
+    sp.pages(raws[0], strategies, hw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = [sp.pages(r, strategies, hw) for r in raws]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_probe
+    same = all(torch.equal(o, host_pages[p * reads_per_page + k]) for p, page in enumerate(outs) for k, o in enumerate(page))
+    return {"s_per_page": dt, "identical_to_host_path": bool(same), "pages_probed": n_probe}
+
+
 def cpu_baseline(cfg, side: int, n_out: int, reads_per_page: int) -> dict:
     """The reference's CPU path, restated (oracle/) and timed on this host on a bounded sample: full Qwen2-VL-2B
     widths, 1 and 2 layers of each stack timed and extrapolated linearly in depth, a few decode steps, strings at full
@@ -328,6 +352,7 @@ def main() -> None:
     eng.collect_timings = True
     tok = tokenizer.ByteTokenizer(cfg, fold_unknown=True)
     pages, prompts, host_prep_s = build_inputs(cfg, args.pages, 1000 * rank, args.reads, args.side, dev)
+    dev_prep = device_preprocess_probe(cfg, pages, 1000 * rank, args.reads, args.side, dev) if rank == 0 else None
     lib = _lib.hip()
 
     def step():
@@ -413,6 +438,7 @@ def main() -> None:
         "decode_roofline": {"bound": "hbm", "bytes_per_step": w_bytes + kv_bytes, "achieved": (w_bytes + kv_bytes) / (dec_ms * 1e-3) / 1e9,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (w_bytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "host_preprocess_s_per_page": host_prep_s / args.pages,
+        "device_preprocess": dev_prep,  # the same strategy reads made on the device (HWOCR_GPU_PREPROCESS path); outside `value` too
     }
     if world == 1 and not args.no_cpu_baseline:
         del eng, pages
