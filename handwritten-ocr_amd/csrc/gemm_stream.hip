@@ -46,7 +46,13 @@ __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of t
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // more than 12 never occurs (<= 3 tiles x 4 instructions)
   }
 }
 
@@ -55,8 +61,14 @@ __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of t
 // waves reading the whole x tile is 288 KB of ds_read per K tile at 128 rows - as long as the DMA of that K tile takes).
 // Staging is independent of that split: wave w brings in weight tile w of the group and x rows {8(w + 16e)}.
 // grid = (tile groups, K slices).
-template <int MT, int EPI, int MSPLIT>
+// WT: weight tiles a workgroup can own (its LDS slots).  The 16-row-tile form (129..256 rows) exists only with WT = 4 or 8:
+// its x tile alone is 32 KiB per K tile, and the weight slots a workgroup does not use (it usually owns 2-5 tiles: N / 16
+// tiles over 256 / splitk groups) are what pays for a third and fourth stage.  Why it exists beside gemm_stream256_kernel:
+// that kernel's loop SKELETON (counted wait + 16-wave barrier + DMA issue per 32-wide K tile) measures 31 of the 41 us of the 2B
+// gate/up GEMM with every byte and every MFMA removed; 64-wide K tiles halve the number of trips.
+template <int MT, int EPI, int MSPLIT, int WT = WG_TILES>
 __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
+  constexpr int WBYTES = WT * 2048;                 // (shadows the 16-tile constant)
   constexpr int NWN = WAVES / MSPLIT;               // waves along N
   constexpr int NTW = WG_TILES / NWN;               // weight tiles per wave (= MSPLIT)
   constexpr int MTW = MT / MSPLIT;                  // row tiles per wave
@@ -64,7 +76,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
   constexpr int XPW = (XFR + WAVES - 1) / WAVES;    // staged per wave
   constexpr int XBYTES = XFR * 1024;
   constexpr int STAGE = XBYTES + WBYTES;
-  constexpr int NSTAGE = 3 * STAGE <= 160 * 1024 ? 3 : 2;
+  constexpr int NSTAGE = MT == 16 ? (4 * STAGE <= 160 * 1024 ? 4 : 3) : (3 * STAGE <= 160 * 1024 ? 3 : 2);
+  static_assert(NSTAGE * STAGE <= 160 * 1024, "ring does not fit in LDS");
   constexpr int DIST = NSTAGE - 1;                  // K tiles in flight ahead of the one being multiplied
   static_assert(MT % MSPLIT == 0 && (MSPLIT == 1 || MSPLIT == 2), "row tiles split evenly over the wave rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,6 +137,26 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     if (t + DIST < nk) issue(t + DIST);            // into the slot K tile t-1 occupied
     const char* st = smem + (t % NSTAGE) * STAGE;
+    if (mine == 0) continue;  // wave columns without a tile read no fragments (16 KiB per wave and K tile at 16 row tiles)
+    if constexpr (MT == 16) {
+      // 4 waves per SIMD = 128 registers: 64 accumulators leave room for ONE 32-wide half of the fragments at a time
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bf16x8 xh[MTW], wh[NTW];
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+          xh[i] = *(const bf16x8*)(st + (16 * (wm * MTW + i) + c) * 128 + (((4 * h + q) ^ (c & 7)) << 4));
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) wh[j] = *(const bf16x8*)(st + XBYTES + (wn * NTW + j) * 2048 + h * 1024 + lane * 16);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+          if (j < mine) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xh[i], acc[j][i], 0, 0, 0);
+          }
+      }
+      continue;
+    }
     bf16x8 xf[MTW][2], wf[NTW][2];
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
@@ -314,25 +347,26 @@ void launch256(const StreamArgs& a, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((gemm_stream256_kernel<EPI>), grid, dim3(64 * WAVES), LDS, st, a);
 }
 
-template <int MT, int EPI, int MSPLIT>
+template <int MT, int EPI, int MSPLIT, int WT>
 void launch_one(const StreamArgs& a, dim3 grid, hipStream_t st) {
-  constexpr int STAGE = 2 * MT * 1024 + WBYTES;
-  constexpr int LDS = (3 * STAGE <= 160 * 1024 ? 3 : 2) * STAGE;
+  constexpr int STAGE = 2 * MT * 1024 + WT * 2048;
+  constexpr int LDS = (MT == 16 ? (4 * STAGE <= 160 * 1024 ? 4 : 3) : (3 * STAGE <= 160 * 1024 ? 3 : 2)) * STAGE;
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<MT, EPI, MSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<MT, EPI, MSPLIT, WT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS);
     done = true;
   }
-  hipLaunchKernelGGL((gemm_stream_kernel<MT, EPI, MSPLIT>), grid, dim3(64 * WAVES), LDS, st, a);
+  hipLaunchKernelGGL((gemm_stream_kernel<MT, EPI, MSPLIT, WT>), grid, dim3(64 * WAVES), LDS, st, a);
 }
 
-template <int MT, int MSPLIT>
+template <int MT, int MSPLIT, int WT = WG_TILES>
 int launch_mt(const StreamArgs& a, int epi, dim3 grid, hipStream_t st) {
   switch (epi) {
-    case EPI_LINEAR: launch_one<MT, EPI_LINEAR, MSPLIT>(a, grid, st); break;
-    case EPI_SWIGLU: launch_one<MT, EPI_SWIGLU, MSPLIT>(a, grid, st); break;
-    case EPI_GEGLU: launch_one<MT, EPI_GEGLU, MSPLIT>(a, grid, st); break;
-    case EPI_PARTIAL: launch_one<MT, EPI_PARTIAL, MSPLIT>(a, grid, st); break;
+    case EPI_LINEAR: launch_one<MT, EPI_LINEAR, MSPLIT, WT>(a, grid, st); break;
+    case EPI_SWIGLU: launch_one<MT, EPI_SWIGLU, MSPLIT, WT>(a, grid, st); break;
+    case EPI_GEGLU: launch_one<MT, EPI_GEGLU, MSPLIT, WT>(a, grid, st); break;
+    case EPI_PARTIAL: launch_one<MT, EPI_PARTIAL, MSPLIT, WT>(a, grid, st); break;
     default: return HWOCR_EINVAL;
   }
   return hwocr_launch_status();
@@ -364,6 +398,12 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
   if (mt <= 2) return launch_mt<2, 1>(a, epi, grid, stream);
   if (mt <= 4) return launch_mt<4, 1>(a, epi, grid, stream);
   if (mt <= 8) return split8 == 2 ? launch_mt<8, 2>(a, epi, grid, stream) : launch_mt<8, 1>(a, epi, grid, stream);
+  // 129..256 rows.  A workgroup that owns at most 8 weight tiles (every decoder GEMM of the 2B / 3B / 7B shapes; not the LM
+  // head) takes the 64-wide-K form with 4 or 3 stages; HWOCR_STREAM_K64=0: always the 32-wide-K kernel
+  static const bool k64 = [] { const char* e = getenv("HWOCR_STREAM_K64"); return !e || atoi(e) != 0; }();
+  const int tiles_per_wg = ((units + groups - 1) / groups) * unit;
+  if (k64 && tiles_per_wg <= 4) return launch_mt<16, 2, 4>(a, epi, grid, stream);
+  if (k64 && tiles_per_wg <= 8) return launch_mt<16, 2, 8>(a, epi, grid, stream);
   switch (epi) {
     case EPI_LINEAR: launch256<EPI_LINEAR>(a, grid, stream); break;
     case EPI_SWIGLU: launch256<EPI_SWIGLU>(a, grid, stream); break;
