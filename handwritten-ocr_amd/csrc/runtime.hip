@@ -35,10 +35,14 @@ inline int pick_splitk(int K, int N, int want_wgs) {
 // (x bytes into the CUs = 64 KiB x K / splitk against 1 KiB x N x splitk of slab): measured best 8 slabs, 12 for the
 // long-K / narrow-N down projection, and slices of at least 6 K tiles (K = 1536: 4 slabs; GEMM + the slab-summing consumer,
 // tools/bench_decode_gemm.py sweep at 126 and 252 reads)
-inline int pick_splitk_stream(int K, int N) {
+// Above 128 reads the 64-wide-K kernel wants at most 8 weight tiles per workgroup (N/16 tiles over 256/s groups): the split is
+// lowered until that holds (7B down projection: 12 -> 9 slabs, 64 -> 56 us with its slab-summing consumer).
+inline int pick_splitk_stream(int K, int N, int rows) {
   const int ktiles = K / 64;
   int s = K >= 4 * N ? 12 : 8;
   if (s > ktiles / 6) s = ktiles / 6;
+  if (rows > 128)
+    while (s > 1 && (N / 16) * s > 8 * 256) --s;
   if (s < 1) s = 1;
   const int per = (ktiles + s - 1) / s;  // every slice must own at least one K tile
   return (ktiles + per - 1) / per;
@@ -213,9 +217,9 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   const float scale = 1.0f / sqrtf((float)HD);
   bool stream = (Hd % 64) == 0 && (OW % 64) == 0 && (m->inter % 64) == 0;
   for (int l = 0; l < m->layers && stream; ++l) stream = m->L[l].qkv_wt && m->L[l].o_wt && m->L[l].down_wt;
-  const int s_qkv = stream ? pick_splitk_stream(Hd, QW) : pick_splitk(Hd, QW, 400);
-  const int s_o = stream ? pick_splitk_stream(OW, Hd) : pick_splitk(OW, Hd, 400);
-  const int s_d = stream ? pick_splitk_stream(m->inter, Hd) : pick_splitk(m->inter, Hd, 400);
+  const int s_qkv = stream ? pick_splitk_stream(Hd, QW, nseq) : pick_splitk(Hd, QW, 400);
+  const int s_o = stream ? pick_splitk_stream(OW, Hd, nseq) : pick_splitk(OW, Hd, 400);
+  const int s_d = stream ? pick_splitk_stream(m->inter, Hd, nseq) : pick_splitk(m->inter, Hd, 400);
   CHECK(hwocr_embed_splice(gs->cur_ids, nullptr, m->embed, nullptr, ws->h, nseq, Hd, G ? m->embed_scale : 1.0f, st));
   CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->L[0].in_norm_w, ws->hn, Hd, nullptr, nseq, Hd,
                           m->eps, G, st));
