@@ -25,6 +25,9 @@
 // A variant with the weights HBM -> VGPR in a 4-deep hand-unrolled register ring (exact compiler vmcnt waits once the
 // loop has no separate prologue and no load under a t-dependent branch) and x by plain loads + ds_write moved bytes into
 // the CUs at the same rate but re-read weight tiles for idle waves: 3.3 TB/s; dropped.
+// Later finding (252 rows): the cost is per loop trip and per DMA instruction rather than per byte - the 32-wide-K kernel's
+// skeleton alone (4-byte DMAs, no fragment reads, no MFMA) takes 31 of the 41 us of the 2B gate/up GEMM, about 33 1-KiB DMA
+// instructions per us per CU - hence the 64-wide-K form with 16 row tiles below (gemm_stream_kernel<16, EPI, 2, WT>).
 // Epilogues as gemm_skinny: PARTIAL fp32 split-K slabs, LINEAR (+bias), SWIGLU / GEGLU on interleaved gate/up tile pairs.
 #include "gemm_common.cuh"
 #include <cstdlib>
