@@ -64,7 +64,7 @@ __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of t
 // waves reading the whole x tile is 288 KB of ds_read per K tile at 128 rows - as long as the DMA of that K tile takes).
 // Staging is independent of that split: wave w brings in weight tile w of the group and x rows {8(w + 16e)}.
 // grid = (tile groups, K slices).
-// WT: weight tiles a workgroup can own (its LDS slots).  The 16-row-tile form (129..256 rows) exists only with WT = 4 or 8:
+// WT: weight tiles a workgroup can own (its LDS slots).  The 16-row-tile form (129..256 rows) exists only with WT = 4, 8 or 10:
 // its x tile alone is 32 KiB per K tile, and the weight slots a workgroup does not use (it usually owns 2-5 tiles: N / 16
 // tiles over 256 / splitk groups) are what pays for a third and fourth stage.  Why it exists beside gemm_stream256_kernel:
 // that kernel's loop SKELETON (counted wait + 16-wave barrier + DMA issue per 32-wide K tile) measures 31 of the 41 us of the 2B
@@ -401,12 +401,13 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
   if (mt <= 2) return launch_mt<2, 1>(a, epi, grid, stream);
   if (mt <= 4) return launch_mt<4, 1>(a, epi, grid, stream);
   if (mt <= 8) return split8 == 2 ? launch_mt<8, 2>(a, epi, grid, stream) : launch_mt<8, 1>(a, epi, grid, stream);
-  // 129..256 rows.  A workgroup that owns at most 8 weight tiles (every decoder GEMM of the 2B / 3B / 7B shapes; not the LM
+  // 129..256 rows.  A workgroup that owns at most 10 weight tiles (every decoder GEMM of the 2B / 3B / 7B shapes; not the LM
   // head) takes the 64-wide-K form with 4 or 3 stages; HWOCR_STREAM_K64=0: always the 32-wide-K kernel
   static const bool k64 = [] { const char* e = getenv("HWOCR_STREAM_K64"); return !e || atoi(e) != 0; }();
   const int tiles_per_wg = ((units + groups - 1) / groups) * unit;
   if (k64 && tiles_per_wg <= 4) return launch_mt<16, 2, 4>(a, epi, grid, stream);
   if (k64 && tiles_per_wg <= 8) return launch_mt<16, 2, 8>(a, epi, grid, stream);
+  if (k64 && tiles_per_wg <= 10) return launch_mt<16, 2, 10>(a, epi, grid, stream);  // 52 KiB stages, 3 of them (7B gate/up: 5 pairs)
   switch (epi) {
     case EPI_LINEAR: launch256<EPI_LINEAR>(a, grid, stream); break;
     case EPI_SWIGLU: launch256<EPI_SWIGLU>(a, grid, stream); break;
