@@ -99,6 +99,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
   const bool stage_w = t0 + w < t1;                 // this wave stages tile t0 + w
   const int kt0 = blockIdx.y * a.ktiles_per_slice;
   const int nk = min(a.ktiles_per_slice, (a.K >> 6) - kt0);
+  const int r0 = blockIdx.z * (16 * MT);            // row block (grid.z = 2: 129..256 rows as two blocks of 128, see launcher)
 
   // ---- DMA sources.  x instruction f stages rows 8f .. 8f+7: lane l <- 16-byte chunk (l&7) ^ (l>>3) of row 8f + (l>>3),
   // so chunk ch of row r sits at LDS position ch ^ (r & 7) of its 128-byte row
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
 #pragma unroll
   for (int e = 0; e < XPW; ++e) {
     const int f = w + WAVES * e;
-    xsrc[e] = a.X + (size_t)min(8 * f + (lane >> 3), a.Bsz - 1) * a.ldx + (size_t)kt0 * 64 + 8 * ((lane & 7) ^ (lane >> 3));
+    xsrc[e] = a.X + (size_t)min(r0 + 8 * f + (lane >> 3), a.Bsz - 1) * a.ldx + (size_t)kt0 * 64 + 8 * ((lane & 7) ^ (lane >> 3));
   }
   const bf16* wsrc = a.W + ((size_t)(t0 + w) * (a.K >> 5) + (size_t)kt0 * 2) * 512 + lane * 8;  // + t*1024 + h*512
   const int n_dma = (XFR > w ? (XFR - w + WAVES - 1) / WAVES : 0) + (stage_w ? 2 : 0);  // DMA instructions per stage
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
     if (!(w & 1) && mine > 0) {
 #pragma unroll
       for (int i = 0; i < MTW; ++i) {
-        const int m = 16 * i + c;
+        const int m = r0 + 16 * i + c;
         const f32x4 up = *(const f32x4*)(xch + (i * 64 + lane) * 4);
         if (m < a.Bsz) {
           bf16x4 o;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
   }
 #pragma unroll
   for (int i = 0; i < MTW; ++i) {
-    const int m = 16 * (wm * MTW + i) + c;
+    const int m = r0 + 16 * (wm * MTW + i) + c;
     if (m >= a.Bsz) continue;
     if constexpr (is_glu<EPI>) {
 #pragma unroll
@@ -405,6 +406,17 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
   // head) takes the 64-wide-K form with 4 or 3 stages; HWOCR_STREAM_K64=0: always the 32-wide-K kernel
   static const bool k64 = [] { const char* e = getenv("HWOCR_STREAM_K64"); return !e || atoi(e) != 0; }();
   const int tiles_per_wg = ((units + groups - 1) / groups) * unit;
+  // What a workgroup pulls in per K tile is cache lines: 16 rows-tiles x 16 lines of x + 16 lines per weight tile.  Below 8
+  // tiles per workgroup two row blocks of 128 (grid.z = 2, half as many tile groups, so twice the tiles each) need fewer:
+  // 128 + 32 t against 256 + 16 t lines (2B gate/up: 268 vs 326).  HWOCR_STREAM_R2=0 disables.
+  static const bool r2 = [] { const char* e = getenv("HWOCR_STREAM_R2"); return !e || atoi(e) != 0; }();
+  if (k64 && r2 && tiles_per_wg < 8) {
+    int g2 = 256 / (2 * splitk);  // never more than one round of workgroups (a few left over for a second round cost a whole trip count)
+    if (g2 < 1) g2 = 1;
+    if (g2 > units) g2 = units;
+    while ((units + g2 - 1) / g2 > per_wg) ++g2;
+    return launch_mt<8, 2>(a, epi, dim3(g2, splitk, 2), stream);
+  }
   if (k64 && tiles_per_wg <= 4) return launch_mt<16, 2, 4>(a, epi, grid, stream);
   if (k64 && tiles_per_wg <= 8) return launch_mt<16, 2, 8>(a, epi, grid, stream);
   if (k64 && tiles_per_wg <= 10) return launch_mt<16, 2, 10>(a, epi, grid, stream);  // 52 KiB stages, 3 of them (7B gate/up: 5 pairs)

@@ -39,7 +39,9 @@ inline int pick_splitk(int K, int N, int want_wgs) {
 // lowered until that holds (7B down projection: 12 -> 9 slabs, 64 -> 56 us with its slab-summing consumer).
 inline int pick_splitk_stream(int K, int N, int rows) {
   const int ktiles = K / 64;
-  int s = K >= 4 * N ? 12 : 8;
+  // above 128 reads (two row blocks per weight-tile group, gemm_stream.hip) fewer, longer slices win: sweep at 252 reads,
+  // GEMM + slab-summing consumer: 2B down 8-10 slabs 21.3 us (12: 22.7), 7B o 4 slabs 20.2 (8: 26.2), 7B qkv 4: 17.2 (7: 18.6)
+  int s = K >= 4 * N ? (rows > 128 ? 8 : 12) : (rows > 128 ? 4 : 8);
   if (s > ktiles / 6) s = ktiles / 6;
   if (rows > 128)
     while (s > 1 && (N / 16) * s > 8 * 256) --s;
