@@ -672,8 +672,9 @@ class ReadEngine:
                     self._vit_tables, self._vit_lay = t, lay
                     self._vbufs["patches"].zero_()
                     self._vit_layout = layout
-                if isinstance(pages[group[0]], torch.Tensor):  # already resident in HBM
-                    imgs = torch.stack([pages[i] for i in group]).contiguous()
+                if any(isinstance(pages[i], torch.Tensor) for i in group):  # (some) already resident in HBM
+                    imgs = torch.stack([pages[i] if isinstance(pages[i], torch.Tensor) else
+                                        torch.from_numpy(np.ascontiguousarray(pages[i])).to(self.dev) for i in group]).contiguous()
                 else:
                     imgs = torch.from_numpy(np.stack([pages[i] for i in group])).to(self.dev, non_blocking=True)
                 out = torch.empty(rows // mm, c.hidden, dtype=torch.bfloat16, device=self.dev)
