@@ -84,13 +84,17 @@ def test_batched_driver_with_device_preprocessing_gives_the_same_states(tmp_path
         p = tmp_path / f"p{i}.png"
         Image.fromarray(make_page(80 + i, 70, 100), "RGB").save(p)
         paths.append(str(p))
+    # a grey-scale page: the device path only takes plain RGB pages, this one keeps the host path inside the same batch
+    p = tmp_path / "p2.png"
+    Image.fromarray(make_page(82, 70, 100), "RGB").convert("L").save(p)
+    paths.append(str(p))
     params = {"max_new_tokens": 12, "min_new_tokens": 12}
     monkeypatch.setenv("HWOCR_GPU_PREPROCESS", "0")
     host = batch.initial_ocr_batched(paths, params)
     monkeypatch.setenv("HWOCR_GPU_PREPROCESS", "1")
     dev = batch.initial_ocr_batched(paths, params)
     capsys.readouterr()
-    assert len(host) == len(dev) == 2
+    assert len(host) == len(dev) == 3
     for a, b in zip(host, dev):
         assert a["current_best"] == b["current_best"]
         assert [c["text"] for c in a["candidates"]] == [c["text"] for c in b["candidates"]]
