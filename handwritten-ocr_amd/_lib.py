@@ -10,7 +10,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 6  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
+ABI_VERSION = 7  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
 
 P = C.c_void_p
 I = C.c_int
@@ -21,6 +21,8 @@ F = C.c_float
 class HwocrError(RuntimeError):
     pass
 
+
+STATUS_BAD_POSITION = 1  # HWOCR_STATUS_BAD_POSITION
 
 _CODES = {1: "HWOCR_EINVAL (argument rejected by the launcher)", 2: "HWOCR_ELAUNCH (HIP launch failed)"}
 
@@ -80,7 +82,7 @@ class Decoder(C.Structure):
     _fields_ = [(n, I) for n in ("layers", "hidden", "Hq", "Hkv", "inter", "vocab", "sec0", "sec1", "head_dim",
                                  "gemma")] + [
         ("eps", F), ("embed_scale", F), ("embed", P), ("lm_head", P), ("lm_head_t", P), ("final_norm_w", P), ("L", C.POINTER(DecLayer)),
-        ("rope_cos", P), ("rope_sin", P)]
+        ("rope_cos", P), ("rope_sin", P), ("max_pos", I)]
 
 
 class Kv(C.Structure):
@@ -95,7 +97,7 @@ class DecWs(C.Structure):
 class GenState(C.Structure):
     _fields_ = [(n, P) for n in ("cur_ids", "lens", "n_gen", "finished", "out_tokens", "rope_delta")] + [
         ("max_new", I), ("min_new", I), ("n_eos", I), ("pad_id", I), ("eos", I * 4), ("seen", P), ("seen_ld", I),
-        ("rep_penalty", F)]
+        ("rep_penalty", F), ("status", P)]
 
 
 _HIP_SIGS = {
@@ -107,6 +109,9 @@ _HIP_SIGS = {
     "hwocr_rmsnorm_fp8": ([P, I, P, P, P, I, I, I, F, I, P], I),
     "hwocr_gemm_wide_fp8": ([P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P], I),
     "hwocr_gemm_skinny": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P], I),
+    "hwocr_gemm_skinny_variant": ([I, I, I, I, I, I, C.c_char_p, I], I),
+    "hwocr_attn_decode_variant": ([I, I, I, C.c_char_p, I], I),
+    "hwocr_decode_gemm_plan": ([C.POINTER(Decoder), I, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I)], I),
     "hwocr_tile_weights": ([P, P, I, I, I, P], I),
     "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, I, P], I),
     "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, P], I),
@@ -116,7 +121,7 @@ _HIP_SIGS = {
     "hwocr_add_rmsnorm": ([P, I, L, I, P, P, I, P, P, I, P, I, I, F, I, P], I),
     "hwocr_vit_rope_split": ([P, P, P, P, P, P, P, P, I, I, I, I, P], I),
     "hwocr_mrope_kv_prefill": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, I, I, P], I),
-    "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, I, I, P], I),
+    "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, I, I, I, I, P, P], I),
     "hwocr_embed_splice": ([P, P, P, P, P, I, I, F, P], I),
     "hwocr_argmax_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P, I, F, P], I),
     "hwocr_vit_forward": ([C.POINTER(Vit), C.POINTER(VitWs), P, I, I, I, I, C.POINTER(VitLayout), P, P], I),

@@ -13,6 +13,7 @@
 //                 with the usual (m, l, O) rule.
 #include "common.cuh"
 #include "hwocr.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace {
@@ -949,7 +950,8 @@ extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, c
                                  long k_seq, long k_head, long v_seq, long v_head, long v_row, float scale,
                                  int head_dim, int kv_tiled, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
-  if (nseq <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16 || nsplit < 1) return HWOCR_EINVAL;
+  // nsplit <= 16: the partial buffers of hwocr_dec_ws are sized for 16 splits (engine._dec_ws)
+  if (nseq <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16 || nsplit < 1 || nsplit > 16) return HWOCR_EINVAL;
   if (nsplit > 1 && (!part_o || !part_ml)) return HWOCR_EINVAL;
   if ((v_row % 64) || (k_seq % 8) || (k_head % 8) || (v_seq % 8) || (v_head % 8)) return HWOCR_EINVAL;
   if ((head_dim != 128 && head_dim != 256) || (kv_tiled && head_dim != 128)) return HWOCR_EINVAL;
@@ -971,4 +973,13 @@ extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, c
   }
   if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<128>, dim3(Hkv, nseq), dim3(256), 0, stream, a);
   return hwocr_launch_status();
+}
+
+// the kernel instance hwocr_attn_decode runs for these arguments (for the parity tests' coverage check)
+extern "C" int hwocr_attn_decode_variant(int nsplit, int head_dim, int kv_tiled, char* name, int name_len) {
+  if (!name || name_len < 8 || nsplit < 1 || nsplit > 16 || (head_dim != 128 && head_dim != 256) || (kv_tiled && head_dim != 128))
+    return HWOCR_EINVAL;
+  const int waves = (head_dim == 256 || nsplit > 1) ? 4 : 8;
+  snprintf(name, name_len, "attn_decode_kernel<%s,%d,%d>%s", kv_tiled ? "tiled" : "rows", waves, head_dim, nsplit > 1 ? "+merge" : "");
+  return HWOCR_OK;
 }

@@ -423,6 +423,7 @@ struct DecQkvArgs {
   const int* lens; const int* rope_delta;
   const bf16* cos_tab; const bf16* sin_tab;
   int Hq, Hkv; long k_seq, k_head, v_seq, v_head, v_row; int tiled;
+  int ctx, max_pos; int* status;
 };
 template <int DHD>
 __global__ __launch_bounds__(256) void decode_qkv_finish_kernel(DecQkvArgs a) {
@@ -450,8 +451,15 @@ __global__ __launch_bounds__(256) void decode_qkv_finish_kernel(DecQkvArgs a) {
     for (int e = 0; e < 8; ++e) row[ch * 8 + e] = f2bf(y[e]);
   }
   __syncthreads();
+  // Invariants the host keeps (engine.py): 1 <= lens <= ctx and 0 <= lens - 1 + rope_delta < max_pos (all position axes
+  // coincide on generated tokens).  A read that breaks them is NOT repaired here: its row is skipped — no cache write, no
+  // table read outside the allocation — and bit 0 of *status is raised for the host to turn into an error.
   const int slot = a.lens[b] - 1;
-  const int p = max(0, slot + a.rope_delta[b]);  // all position axes coincide on generated tokens (never before the table)
+  const int p = slot + a.rope_delta[b];
+  if (slot < 0 || slot >= a.ctx || p < 0 || p >= a.max_pos) {  // uniform over the workgroup
+    if (tid == 0 && a.status) atomicOr(a.status, HWOCR_STATUS_BAD_POSITION);
+    return;
+  }
   // q and k heads: pairs (d, d + DHD/2)
   for (int id = tid; id < (a.Hq + a.Hkv) * HALF; id += 256) {
     const int hy = id / HALF, i = id % HALF;
@@ -712,12 +720,13 @@ extern "C" int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_
                                        void* K, void* VT, const int* lens, const int* rope_delta,
                                        const void* cos_tab, const void* sin_tab, int nseq, int Hq, int Hkv,
                                        long k_seq, long k_head, long v_seq, long v_head, long v_row, int head_dim,
-                                       int kv_tiled, hipStream_t stream) {
+                                       int kv_tiled, int ctx, int max_pos, int* status, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
-  if (nseq <= 0 || nslab < 1 || !slabs) return HWOCR_EINVAL;
+  if (nseq <= 0 || nslab < 1 || !slabs || ctx < 1 || max_pos < 1) return HWOCR_EINVAL;
   if ((head_dim != 128 && head_dim != 256) || (kv_tiled && head_dim != 128)) return HWOCR_EINVAL;
   DecQkvArgs a{slabs, nslab, slab_stride, (const bf16*)bias, (bf16*)Q, (bf16*)K, (bf16*)VT, lens, rope_delta,
-               (const bf16*)cos_tab, (const bf16*)sin_tab, Hq, Hkv, k_seq, k_head, v_seq, v_head, v_row, kv_tiled};
+               (const bf16*)cos_tab, (const bf16*)sin_tab, Hq, Hkv, k_seq, k_head, v_seq, v_head, v_row, kv_tiled,
+               ctx, max_pos, status};
   const size_t lds = (size_t)(Hq + 2 * Hkv) * head_dim * 2;
   if (head_dim == 128) hipLaunchKernelGGL(decode_qkv_finish_kernel<128>, dim3(nseq), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL(decode_qkv_finish_kernel<256>, dim3(nseq), dim3(256), lds, stream, a);

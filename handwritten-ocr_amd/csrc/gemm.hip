@@ -17,6 +17,7 @@
 // Epilogues reproduce the points where the reference's bf16 modules materialise a tensor
 // (HF modeling_qwen2_vl.py:293-301 VisionMlp, :453-466 Qwen2MLP, :442-448 residual adds).
 #include "gemm_common.cuh"
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -458,40 +459,69 @@ extern "C" int hwocr_tile_weights(const void* src, void* dst, int N, int K, int 
   return hwocr_launch_status();
 }
 
+// Which path a skinny call takes: the streaming kernel (fragment-tiled weights) or gemm_skinny_kernel.  Shared by the
+// launcher and by hwocr_gemm_skinny_variant so that the parity tests can ask what a given call would run.
+namespace {
+bool skinny_args_ok(int Bsz, int N, int K, int ldx, int ldw, int ldo, int epi, int splitk, bool has_bias) {
+  if (Bsz <= 0 || Bsz > 256 || N <= 0 || K <= 0 || (K % 32) || (N % 16) || ((epi == EPI_SWIGLU || epi == EPI_GEGLU) && (N % 32)) ||
+      (ldx % 8) || (ldw % 8) || (ldo % 4) || splitk < 1)
+    return false;
+  if (epi != EPI_PARTIAL && splitk != 1) return false;
+  if ((epi == EPI_SWIGLU || epi == EPI_GEGLU) && has_bias) return false;
+  return true;
+}
+bool skinny_takes_stream(int Bsz, int N, int K, int epi, int splitk, int w_tiled) {
+  // fragment-tiled weights: the LDS-DMA streaming kernel (gemm_stream.hip)
+  static const bool use_stream = [] { const char* e = getenv("HWOCR_GEMM_STREAM"); return !e || atoi(e) != 0; }();
+  if (!(use_stream && w_tiled && Bsz <= 256 && (K % 64) == 0)) return false;
+  const int ktiles = K / 64, per = (ktiles + splitk - 1) / splitk;
+  // a plain linear over more than one round of 16-tile groups (the LM head) re-stages x once per group: the older
+  // kernel's 128-row groups do that cheaper (LM head 2B: 90 us against 104)
+  const bool many_rounds = epi == EPI_LINEAR && N / 16 > 16 * 256 && Bsz <= 128;  // (at 129+ rows the older kernel is slower)
+  return (splitk - 1) * per < ktiles && !many_rounds;
+}
+int skinny_nb(int Bsz) {  // batch tiles of the gemm_skinny_kernel instance that serves Bsz rows
+  const int nb = (Bsz + 15) / 16;
+  return nb <= 4 ? nb : nb <= 6 ? 6 : nb <= 8 ? 8 : nb <= 12 ? 12 : 16;
+}
+}  // namespace
+
+extern "C" int hwocr_gemm_skinny_variant(int Bsz, int N, int K, int epi, int splitk, int w_tiled, char* name, int name_len) {
+  if (!name || name_len < 8 || !skinny_args_ok(Bsz, N, K, K, K, N, epi, splitk, false)) return HWOCR_EINVAL;
+  if (skinny_takes_stream(Bsz, N, K, epi, splitk, w_tiled)) {
+    const char* v = nullptr;
+    const int rc = hwocr_gemm_stream_variant(Bsz, N, K, epi, splitk, &v);
+    if (rc != HWOCR_OK) return rc;
+    snprintf(name, name_len, "%s epi=%d", v, epi);
+    return HWOCR_OK;
+  }
+  const long wg4 = (long)((N + 127) / 128) * splitk;
+  snprintf(name, name_len, "gemm_skinny_kernel<NB=%d,%s,%s> epi=%d", skinny_nb(Bsz), wg4 >= 512 ? "4 waves" : "2 waves",
+           w_tiled ? "tiled" : "rowmajor", epi);
+  return HWOCR_OK;
+}
+
 extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out, int Bsz, int N,
                                  int K, int ldx, int ldw, int ldo, int epi, int splitk, int w_tiled,
                                  hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
-  if (Bsz <= 0 || Bsz > 256 || N <= 0 || K <= 0 || (K % 32) || (N % 16) || ((epi == EPI_SWIGLU || epi == EPI_GEGLU) && (N % 32)) || (ldx % 8) || (ldw % 8) || (ldo % 4) ||
-      splitk < 1)
-    return HWOCR_EINVAL;
-  if (epi != EPI_PARTIAL && splitk != 1) return HWOCR_EINVAL;
-  if ((epi == EPI_SWIGLU || epi == EPI_GEGLU) && bias) return HWOCR_EINVAL;
-  // fragment-tiled weights: the LDS-DMA streaming kernel (gemm_stream.hip)
-  static const bool use_stream = [] { const char* e = getenv("HWOCR_GEMM_STREAM"); return !e || atoi(e) != 0; }();
-  if (use_stream && w_tiled && Bsz <= 256 && (K % 64) == 0) {
-    const int ktiles = K / 64, per = (ktiles + splitk - 1) / splitk;
-    // a plain linear over more than one round of 16-tile groups (the LM head) re-stages x once per group: the older
-    // kernel's 128-row groups do that cheaper (LM head 2B: 90 us against 104)
-    const bool many_rounds = epi == EPI_LINEAR && N / 16 > 16 * 256 && Bsz <= 128;  // (at 129+ rows the older kernel is slower)
-    if ((splitk - 1) * per < ktiles && !many_rounds)
-      return hwocr_gemm_stream(StreamArgs{(const bf16*)X, (const bf16*)W, (const bf16*)bias, out, Bsz, N, K, ldx, ldo, 0},
-                               epi, splitk, stream);
-  }
+  if (!skinny_args_ok(Bsz, N, K, ldx, ldw, ldo, epi, splitk, bias != nullptr)) return HWOCR_EINVAL;
+  if (skinny_takes_stream(Bsz, N, K, epi, splitk, w_tiled))
+    return hwocr_gemm_stream(StreamArgs{(const bf16*)X, (const bf16*)W, (const bf16*)bias, out, Bsz, N, K, ldx, ldo, 0},
+                             epi, splitk, stream);
   // K slice per split: whole 256-element chunks
   int chunks = (K + 255) / 256;
   int per = (chunks + splitk - 1) / splitk;
   SkinnyArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, out, Bsz, N, K, ldx, ldw, ldo, per * 256};
   if ((splitk - 1) * a.kslice >= K) return HWOCR_EINVAL;  // an empty slice would leave its slab unwritten
-  const int nb = (Bsz + 15) / 16;
-  switch (nb) {
+  switch (skinny_nb(Bsz)) {
     case 1: return launch_skinny<1>(a, epi, splitk, w_tiled != 0, stream);
     case 2: return launch_skinny<2>(a, epi, splitk, w_tiled != 0, stream);
     case 3: return launch_skinny<3>(a, epi, splitk, w_tiled != 0, stream);
     case 4: return launch_skinny<4>(a, epi, splitk, w_tiled != 0, stream);
-    case 5: case 6: return launch_skinny<6>(a, epi, splitk, w_tiled != 0, stream);
-    case 7: case 8: return launch_skinny<8>(a, epi, splitk, w_tiled != 0, stream);
-    case 9: case 10: case 11: case 12: return launch_skinny<12>(a, epi, splitk, w_tiled != 0, stream);
+    case 6: return launch_skinny<6>(a, epi, splitk, w_tiled != 0, stream);
+    case 8: return launch_skinny<8>(a, epi, splitk, w_tiled != 0, stream);
+    case 12: return launch_skinny<12>(a, epi, splitk, w_tiled != 0, stream);
     default: return launch_skinny<16>(a, epi, splitk, w_tiled != 0, stream);
   }
 }

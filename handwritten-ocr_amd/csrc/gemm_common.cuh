@@ -113,6 +113,8 @@ struct StreamArgs {
   int Bsz, N, K, ldx, ldo, ktiles_per_slice;
 };
 int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream);
+// the kernel instance hwocr_gemm_stream would run for this shape (static string), without launching anything
+int hwocr_gemm_stream_variant(int Bsz, int N, int K, int epi, int splitk, const char** name);
 
 // launcher of the 256x256 kernel (gemm256.hip); returns HWOCR_EINVAL when the shape does not qualify
 int hwocr_gemm_wide256(const gemm::WideArgs& a, int epi, hipStream_t stream);

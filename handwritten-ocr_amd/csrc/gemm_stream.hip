@@ -64,7 +64,7 @@ __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of t
 // waves reading the whole x tile is 288 KB of ds_read per K tile at 128 rows - as long as the DMA of that K tile takes).
 // Staging is independent of that split: wave w brings in weight tile w of the group and x rows {8(w + 16e)}.
 // grid = (tile groups, K slices).
-// WT: weight tiles a workgroup can own (its LDS slots).  The 16-row-tile form (129..256 rows) exists only with WT = 4, 8 or 10:
+// WT: weight tiles a workgroup can own (its LDS slots).  The 16-row-tile form (129..256 rows) exists only with WT = 8 or 10:
 // its x tile alone is 32 KiB per K tile, and the weight slots a workgroup does not use (it usually owns 2-5 tiles: N / 16
 // tiles over 256 / splitk groups) are what pays for a third and fourth stage.  Why it exists beside gemm_stream256_kernel:
 // that kernel's loop SKELETON (counted wait + 16-wave barrier + DMA issue per 32-wide K tile) measures 31 of the 41 us of the 2B
@@ -379,13 +379,24 @@ int launch_mt(const StreamArgs& a, int epi, dim3 grid, hipStream_t st) {
 }  // namespace
 
 // Shapes this kernel takes: fragment-tiled W, Bsz <= 256, K % 64 == 0, every K slice non-empty.
-int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
-  if (a.Bsz < 1 || a.Bsz > 256 || (a.K % 64) || (a.N % 16) || splitk < 1) return HWOCR_EINVAL;
-  const int ktiles = a.K / 64;
-  a.ktiles_per_slice = (ktiles + splitk - 1) / splitk;
-  if ((splitk - 1) * a.ktiles_per_slice >= ktiles) return HWOCR_EINVAL;  // an empty slice would leave its slab unwritten
+// The choice of kernel instance and grid is made by plan_stream alone, so that hwocr_gemm_stream_variant (what the parity
+// tests ask: "which instance would this call run?") and the launcher cannot disagree.
+namespace {
+enum StreamKind : int { SK_MT1, SK_MT2, SK_MT4, SK_MT8_M1, SK_MT8_M2, SK_MT8_M2_R2, SK_K64_W8, SK_K64_W10, SK_K32_256 };
+const char* const kStreamKindName[] = {
+    "gemm_stream_kernel<1,1,16>",        "gemm_stream_kernel<2,1,16>",  "gemm_stream_kernel<4,1,16>",
+    "gemm_stream_kernel<8,1,16>",        "gemm_stream_kernel<8,2,16>",  "gemm_stream_kernel<8,2,16>/rowblocks2",
+    "gemm_stream_kernel<16,2,8>",        "gemm_stream_kernel<16,2,10>", "gemm_stream256_kernel"};
+struct StreamPlan { int kind; dim3 grid; int ktiles_per_slice; };
+
+int plan_stream(int Bsz, int N, int K, int epi, int splitk, StreamPlan& p) {
+  if (Bsz < 1 || Bsz > 256 || (K % 64) || (N % 16) || splitk < 1) return HWOCR_EINVAL;
+  if (epi != EPI_LINEAR && epi != EPI_SWIGLU && epi != EPI_GEGLU && epi != EPI_PARTIAL) return HWOCR_EINVAL;
+  const int ktiles = K / 64;
+  p.ktiles_per_slice = (ktiles + splitk - 1) / splitk;
+  if ((splitk - 1) * p.ktiles_per_slice >= ktiles) return HWOCR_EINVAL;  // an empty slice would leave its slab unwritten
   const int unit = (epi == EPI_SWIGLU || epi == EPI_GEGLU) ? 2 : 1;
-  const int units = a.N / 16 / unit, per_wg = WG_TILES / unit;
+  const int units = N / 16 / unit, per_wg = WG_TILES / unit;
   // one workgroup per CU: as many tile groups as fill the chip once with this split (more only if a group would exceed
   // 16 tiles; then whole rounds of 256 workgroups)
   int groups = (units + per_wg - 1) / per_wg;
@@ -395,15 +406,15 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
   if (groups > units) groups = units;
   // the balanced split must not hand any group more than per_wg units
   while ((units + groups - 1) / groups > per_wg) ++groups;
-  const dim3 grid(groups, splitk);
-  const int mt = (a.Bsz + 15) / 16;
+  p.grid = dim3(groups, splitk);
+  const int mt = (Bsz + 15) / 16;
   static const int split8 = [] { const char* e = getenv("HWOCR_STREAM_MSPLIT"); return e ? atoi(e) : 2; }();
-  if (mt <= 1) return launch_mt<1, 1>(a, epi, grid, stream);
-  if (mt <= 2) return launch_mt<2, 1>(a, epi, grid, stream);
-  if (mt <= 4) return launch_mt<4, 1>(a, epi, grid, stream);
-  if (mt <= 8) return split8 == 2 ? launch_mt<8, 2>(a, epi, grid, stream) : launch_mt<8, 1>(a, epi, grid, stream);
+  if (mt <= 1) { p.kind = SK_MT1; return HWOCR_OK; }
+  if (mt <= 2) { p.kind = SK_MT2; return HWOCR_OK; }
+  if (mt <= 4) { p.kind = SK_MT4; return HWOCR_OK; }
+  if (mt <= 8) { p.kind = split8 == 2 ? SK_MT8_M2 : SK_MT8_M1; return HWOCR_OK; }
   // 129..256 rows.  A workgroup that owns at most 10 weight tiles (every decoder GEMM of the 2B / 3B / 7B shapes; not the LM
-  // head) takes the 64-wide-K form with 4 or 3 stages; HWOCR_STREAM_K64=0: always the 32-wide-K kernel
+  // head) takes the 64-wide-K form; HWOCR_STREAM_K64=0: always the 32-wide-K kernel
   static const bool k64 = [] { const char* e = getenv("HWOCR_STREAM_K64"); return !e || atoi(e) != 0; }();
   const int tiles_per_wg = ((units + groups - 1) / groups) * unit;
   // What a workgroup pulls in per K tile is cache lines: 16 rows-tiles x 16 lines of x + 16 lines per weight tile.  Below 8
@@ -415,16 +426,45 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
     if (g2 < 1) g2 = 1;
     if (g2 > units) g2 = units;
     while ((units + g2 - 1) / g2 > per_wg) ++g2;
-    return launch_mt<8, 2>(a, epi, dim3(g2, splitk, 2), stream);
+    p.kind = SK_MT8_M2_R2;
+    p.grid = dim3(g2, splitk, 2);
+    return HWOCR_OK;
   }
-  if (k64 && tiles_per_wg <= 4) return launch_mt<16, 2, 4>(a, epi, grid, stream);
-  if (k64 && tiles_per_wg <= 8) return launch_mt<16, 2, 8>(a, epi, grid, stream);
-  if (k64 && tiles_per_wg <= 10) return launch_mt<16, 2, 10>(a, epi, grid, stream);  // 52 KiB stages, 3 of them (7B gate/up: 5 pairs)
+  if (k64 && tiles_per_wg <= 8) { p.kind = SK_K64_W8; return HWOCR_OK; }
+  if (k64 && tiles_per_wg <= 10) { p.kind = SK_K64_W10; return HWOCR_OK; }  // 52 KiB stages, 3 of them (7B gate/up: 5 pairs)
+  p.kind = SK_K32_256;
+  return HWOCR_OK;
+}
+}  // namespace
+
+int hwocr_gemm_stream_variant(int Bsz, int N, int K, int epi, int splitk, const char** name) {
+  StreamPlan p;
+  const int rc = plan_stream(Bsz, N, K, epi, splitk, p);
+  if (rc == HWOCR_OK && name) *name = kStreamKindName[p.kind];
+  return rc;
+}
+
+int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
+  StreamPlan p;
+  const int rc = plan_stream(a.Bsz, a.N, a.K, epi, splitk, p);
+  if (rc != HWOCR_OK) return rc;
+  a.ktiles_per_slice = p.ktiles_per_slice;
+  switch (p.kind) {
+    case SK_MT1: return launch_mt<1, 1>(a, epi, p.grid, stream);
+    case SK_MT2: return launch_mt<2, 1>(a, epi, p.grid, stream);
+    case SK_MT4: return launch_mt<4, 1>(a, epi, p.grid, stream);
+    case SK_MT8_M1: return launch_mt<8, 1>(a, epi, p.grid, stream);
+    case SK_MT8_M2:
+    case SK_MT8_M2_R2: return launch_mt<8, 2>(a, epi, p.grid, stream);
+    case SK_K64_W8: return launch_mt<16, 2, 8>(a, epi, p.grid, stream);
+    case SK_K64_W10: return launch_mt<16, 2, 10>(a, epi, p.grid, stream);
+    default: break;
+  }
   switch (epi) {
-    case EPI_LINEAR: launch256<EPI_LINEAR>(a, grid, stream); break;
-    case EPI_SWIGLU: launch256<EPI_SWIGLU>(a, grid, stream); break;
-    case EPI_GEGLU: launch256<EPI_GEGLU>(a, grid, stream); break;
-    case EPI_PARTIAL: launch256<EPI_PARTIAL>(a, grid, stream); break;
+    case EPI_LINEAR: launch256<EPI_LINEAR>(a, p.grid, stream); break;
+    case EPI_SWIGLU: launch256<EPI_SWIGLU>(a, p.grid, stream); break;
+    case EPI_GEGLU: launch256<EPI_GEGLU>(a, p.grid, stream); break;
+    case EPI_PARTIAL: launch256<EPI_PARTIAL>(a, p.grid, stream); break;
     default: return HWOCR_EINVAL;
   }
   return hwocr_launch_status();

@@ -208,20 +208,50 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
   return HWOCR_OK;
 }
 
+
+// split-K of the three slab-producing GEMMs of a decode step (qkv, o, down) at `nseq` reads in flight
+static void decode_splits(const hwocr_decoder* m, int nseq, int& s_qkv, int& s_o, int& s_d) {
+  const int HD = m->head_dim, Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
+  bool stream = (Hd % 64) == 0 && (OW % 64) == 0 && (m->inter % 64) == 0;
+  for (int l = 0; l < m->layers && stream; ++l) stream = m->L[l].qkv_wt && m->L[l].o_wt && m->L[l].down_wt;
+  s_qkv = stream ? pick_splitk_stream(Hd, QW, nseq) : pick_splitk(Hd, QW, 400);
+  s_o = stream ? pick_splitk_stream(OW, Hd, nseq) : pick_splitk(OW, Hd, 400);
+  s_d = stream ? pick_splitk_stream(m->inter, Hd, nseq) : pick_splitk(m->inter, Hd, 400);
+}
+
+// The GEMM calls hwocr_decode_step makes for layer 0 (every layer has the same shapes) and for the LM head, as arguments of
+// hwocr_gemm_skinny: which = 0 qkv, 1 o, 2 gate/up, 3 down, 4 LM head.  For the parity tests: "is there an oracle case for
+// the kernel instance the bench's decode step runs?" (answered together with hwocr_gemm_skinny_variant).
+extern "C" int hwocr_decode_gemm_plan(const hwocr_decoder* m, int nseq, int which, int* N, int* K, int* epi, int* splitk,
+                                      int* w_tiled) {
+  if (!m || !m->L || nseq <= 0 || nseq > 256 || which < 0 || which > 4 || !N || !K || !epi || !splitk || !w_tiled)
+    return HWOCR_EINVAL;
+  const int HD = m->head_dim, Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
+  int s_qkv, s_o, s_d;
+  decode_splits(m, nseq, s_qkv, s_o, s_d);
+  const hwocr_dec_layer& L = m->L[0];
+  switch (which) {
+    case 0: *N = QW, *K = Hd, *epi = HWOCR_EPI_PARTIAL, *splitk = s_qkv, *w_tiled = L.qkv_wt != nullptr; break;
+    case 1: *N = Hd, *K = OW, *epi = HWOCR_EPI_PARTIAL, *splitk = s_o, *w_tiled = L.o_wt != nullptr; break;
+    case 2: *N = 2 * m->inter, *K = Hd, *epi = m->gemma ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, *splitk = 1,
+            *w_tiled = L.gate_up_wt != nullptr; break;
+    case 3: *N = Hd, *K = m->inter, *epi = HWOCR_EPI_PARTIAL, *splitk = s_d, *w_tiled = L.down_wt != nullptr; break;
+    default: *N = m->vocab, *K = Hd, *epi = HWOCR_EPI_LINEAR, *splitk = 1, *w_tiled = m->lm_head_t != nullptr; break;
+  }
+  return HWOCR_OK;
+}
+
 extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
                                  const hwocr_gen_state* gs, int nseq, int attn_splits, hipStream_t st) {
-  if (!m || !ws || !kv || !gs || nseq <= 0 || nseq > 256 || nseq > kv->nseq_max || attn_splits < 1 ||
-      (m->head_dim != 128 && m->head_dim != 256) || (m->head_dim != 128 && kv->tiled))
+  if (!m || !ws || !kv || !gs || nseq <= 0 || nseq > 256 || nseq > kv->nseq_max || attn_splits < 1 || attn_splits > 16 ||
+      m->max_pos < 1 || (m->head_dim != 128 && m->head_dim != 256) || (m->head_dim != 128 && kv->tiled))
     return HWOCR_EINVAL;
   const int HD = m->head_dim, G = m->gemma;
   const int Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
   const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
   const float scale = 1.0f / sqrtf((float)HD);
-  bool stream = (Hd % 64) == 0 && (OW % 64) == 0 && (m->inter % 64) == 0;
-  for (int l = 0; l < m->layers && stream; ++l) stream = m->L[l].qkv_wt && m->L[l].o_wt && m->L[l].down_wt;
-  const int s_qkv = stream ? pick_splitk_stream(Hd, QW, nseq) : pick_splitk(Hd, QW, 400);
-  const int s_o = stream ? pick_splitk_stream(OW, Hd, nseq) : pick_splitk(OW, Hd, 400);
-  const int s_d = stream ? pick_splitk_stream(m->inter, Hd, nseq) : pick_splitk(m->inter, Hd, 400);
+  int s_qkv, s_o, s_d;
+  decode_splits(m, nseq, s_qkv, s_o, s_d);
   CHECK(hwocr_embed_splice(gs->cur_ids, nullptr, m->embed, nullptr, ws->h, nseq, Hd, G ? m->embed_scale : 1.0f, st));
   CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->L[0].in_norm_w, ws->hn, Hd, nullptr, nseq, Hd,
                           m->eps, G, st));
@@ -233,7 +263,7 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
                             HWOCR_EPI_PARTIAL, s_qkv, L.qkv_wt != nullptr, st));
     CHECK(hwocr_decode_qkv_finish(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, ws->q, Kc, Vc, gs->lens, gs->rope_delta,
                                   m->rope_cos, m->rope_sin, nseq, m->Hq, m->Hkv, k_seq, k_head, k_seq, k_head,
-                                  kv->ctx, HD, kv->tiled, st));
+                                  kv->ctx, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
     CHECK(hwocr_attn_decode(ws->q, Kc, Vc, gs->lens, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv,
                             attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, HD, kv->tiled, st));
     CHECK(hwocr_gemm_skinny(ws->attn, L.o_wt ? L.o_wt : L.o_w, nullptr, ws->slabs, nseq, Hd, OW, OW, OW, Hd,

@@ -313,18 +313,59 @@ def _ceil(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def pick_attn_splits(reads: int, kv_heads: int) -> int:
+    """Context splits of the decode attention: one 8-wave workgroup per (read, kv head) once those alone fill the chip,
+    else 4-wave workgroups over 2..16 context splits + a merge launch."""
+    return 1 if reads * kv_heads >= 160 else max(2, min(16, 768 // max(1, reads * kv_heads)))
+
+
+DECODE_GEMMS = ("qkv", "o", "gate_up", "down", "lm_head")
+
+
+def decode_plan(cfg: ModelConfig, reads: int) -> dict:
+    """Kernel instances one decode step of `cfg` runs at `reads` reads in flight: {gemm name: (N, K, epi, splitk, variant)}
+    for the five GEMMs + "attn": variant.  Host-only (asks the library's own launch planner; nothing is launched)."""
+    lib = _lib.hip()
+    layer = (_lib.DecLayer * 1)()
+    one = C.c_void_p(1)  # non-NULL: the engine always binds the fragment-tiled copies
+    layer[0].qkv_wt = layer[0].o_wt = layer[0].gate_up_wt = layer[0].down_wt = one
+    dec = _lib.Decoder(layers=1, hidden=cfg.hidden, Hq=cfg.q_heads, Hkv=cfg.kv_heads, inter=cfg.inter, vocab=cfg.vocab,
+                       head_dim=cfg.head_dim, gemma=1 if cfg.family == "paligemma" else 0, lm_head_t=one, L=layer)
+    out = {}
+    buf = C.create_string_buffer(128)
+    for which, name in enumerate(DECODE_GEMMS):
+        N, K, epi, sk, tiled = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(lib.hwocr_decode_gemm_plan(C.byref(dec), reads, which, C.byref(N), C.byref(K), C.byref(epi), C.byref(sk),
+                                              C.byref(tiled)), "hwocr_decode_gemm_plan")
+        _lib.check(lib.hwocr_gemm_skinny_variant(reads, N.value, K.value, epi.value, sk.value, tiled.value, buf, len(buf)),
+                   "hwocr_gemm_skinny_variant")
+        out[name] = (N.value, K.value, epi.value, sk.value, buf.value.decode())
+    _lib.check(lib.hwocr_attn_decode_variant(pick_attn_splits(reads, cfg.kv_heads), cfg.head_dim, 1 if cfg.head_dim == 128 else 0,
+                                             buf, len(buf)), "hwocr_attn_decode_variant")
+    out["attn"] = buf.value.decode()
+    return out
+
+
 class ReadEngine:
-    def __init__(self, cfg: ModelConfig, state_dict: dict, max_reads: int = 96, ctx: int = 2048, device: str = "cuda:0",
+    VIT_MAX_GRID = 2048  # rows of the vision rotary table: the longest page side in patches (smart_resize admits 200:1 strips:
+    #                      sqrt(1024^2 * 200) / 14 = 1035 patches at the reference's max_pixels); encode_pages checks it
+    MAX_GRAPHS = 8  # captured decode graphs kept (one per distinct reads-in-flight / generation setting), least recently used out
+
+    def __init__(self, cfg: ModelConfig, state_dict: dict, max_reads: int = 96, ctx: int = 2048, device: str | None = None,
                  vit_batch: int = 8, prefill_batch: int = 16, attn_splits: int = 0, fp8: bool = False):
-        """fp8: run the wide GEMMs of the vision tower and of the decoder prefill (K a multiple of 128) on E4M3 copies of
-        the weights with per-token activation scales (BASELINE config 4); norms, attention, decode steps stay bf16."""
+        """device: None = the process's current device (one process per GPU: shard.init_from_env has already made
+        LOCAL_RANK's device current).  fp8: run the wide GEMMs of the vision tower and of the decoder prefill (K a multiple
+        of 128) on E4M3 copies of the weights with per-token activation scales (BASELINE config 4); norms, attention, decode
+        steps stay bf16."""
         cfg.validate()
         if not torch.cuda.is_available():
             raise _lib.HwocrError("ReadEngine needs an MI355X (ROCm) device: there is no CPU path")
         if max_reads < 1 or max_reads > 256:
             raise ValueError("max_reads must be in 1..256 (one decode batch)")
+        if attn_splits < 0 or attn_splits > 16:
+            raise ValueError("attn_splits must be 0 (automatic) or 1..16 (the partial buffers hold 16 splits)")
         self.cfg = cfg
-        self.dev = torch.device(device)
+        self.dev = torch.device(f"cuda:{torch.cuda.current_device()}" if device is None else device)
         torch.cuda.set_device(self.dev)
         self.lib = _lib.hip()
         self.max_reads = max_reads
@@ -482,7 +523,7 @@ class ReadEngine:
         # vision rotary table, fp32, exactly as the library builds it (positions * inv_freq, then cos/sin)
         hd = c.vit_hd
         inv = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float) / (hd // 2)))
-        ang = torch.arange(512, dtype=torch.float).unsqueeze(-1) * inv
+        ang = torch.arange(self.VIT_MAX_GRID, dtype=torch.float).unsqueeze(-1) * inv
         self.vit_cos = ang.cos().contiguous().to(self.dev)
         self.vit_sin = ang.sin().contiguous().to(self.dev)
         self.lut = torch.from_numpy(imageproc.pixel_lut()).to(torch.bfloat16).to(self.dev)
@@ -535,7 +576,7 @@ class ReadEngine:
                                 sec0=sec0, sec1=sec1, head_dim=HD, gemma=1 if gemma else 0, eps=c.eps,
                                 embed_scale=float(c.hidden) ** 0.5,
                                 embed=P(embed), lm_head=P(head), lm_head_t=P(self._tiled(head)), final_norm_w=P(self._t(sd[t + "norm.weight"])), L=layers,
-                                rope_cos=P(self.dec_cos), rope_sin=P(self.dec_sin))
+                                rope_cos=P(self.dec_cos), rope_sin=P(self.dec_sin), max_pos=int(ang.shape[0]))
         self._keep.append(layers)
         self.embed_weight = embed
 
@@ -556,6 +597,7 @@ class ReadEngine:
         self.n_gen = torch.zeros(R, **i32)
         self.finished = torch.zeros(R, **i32)
         self.rope_delta = torch.zeros(R, **i32)
+        self.status = torch.zeros(1, **i32)  # HWOCR_STATUS_* bits raised on the device (hwocr_gen_state.status)
         self.out_tokens = None
         self._seen = None
         self._tok_bufs = {}
@@ -608,6 +650,26 @@ class ReadEngine:
             self._vit_layout = None
         return self._vws
 
+    def _check_status(self) -> None:
+        """After a synchronisation: did a decode step meet a read outside its invariants (position before / past the rope
+        table, cache slot outside the cache)?  The kernels skip such a read instead of repairing it; here it becomes an error."""
+        bits = int(self.status.item())
+        if bits:
+            self.status.zero_()
+            raise _lib.HwocrError(f"decode step reported status {bits:#x} (HWOCR_STATUS_BAD_POSITION: a read's lens / rope_delta "
+                                  "left the cache or the rope table); the reads of this call are invalid")
+
+    def _remember_graph(self, key, g) -> None:
+        """Keep a captured decode graph under `key` (= everything baked into its kernel arguments); least recently used out."""
+        while len(self._graphs) >= self.MAX_GRAPHS:
+            self.lib.hwocr_decode_graph_destroy(self._graphs.pop(next(iter(self._graphs))))
+        self._graphs[key] = g
+
+    def _use_graph(self, key):
+        g = self._graphs.pop(key)
+        self._graphs[key] = g  # most recently used last
+        return g
+
     def _drop_graphs(self) -> None:
         for g in self._graphs.values():
             self.lib.hwocr_decode_graph_destroy(g)
@@ -635,6 +697,10 @@ class ReadEngine:
             by_shape.setdefault((int(p.shape[0]), int(p.shape[1])), []).append(i)
         for (H, W), idxs in by_shape.items():
             gh, gw = H // c.patch_size, W // c.patch_size
+            if H % (c.patch_size * c.merge) or W % (c.patch_size * c.merge) or gh < 1 or gw < 1:
+                raise ValueError(f"page of {H}x{W} pixels is not a whole number of {c.patch_size * c.merge}-pixel merge blocks")
+            if c.family != "paligemma" and max(gh, gw) > self.VIT_MAX_GRID:
+                raise ValueError(f"page grid {gh}x{gw} exceeds the vision rotary table ({self.VIT_MAX_GRID} positions per axis)")
             P = gh * gw
             Pp = _ceil(P, 64)
             ph, pw = imageproc.vision_positions(gh, gw, c.merge)
@@ -764,7 +830,8 @@ class ReadEngine:
                            finished=_lib.ptr(self.finished), out_tokens=_lib.ptr(self.out_tokens),
                            rope_delta=_lib.ptr(self.rope_delta), max_new=max_new, min_new=min_new,
                            n_eos=min(len(c.eos_ids), 4), pad_id=c.pad_id, eos=eos,
-                           seen=_lib.ptr(self._seen) if rp != 1.0 else None, seen_ld=seen_ld, rep_penalty=rp)
+                           seen=_lib.ptr(self._seen) if rp != 1.0 else None, seen_ld=seen_ld, rep_penalty=rp,
+                           status=_lib.ptr(self.status))
         pb = min(self.prefill_batch, R)
         ws = self._dec_ws(max(pb * Tp, self.max_reads))
         step_logits = [] if return_logits else None
@@ -788,10 +855,10 @@ class ReadEngine:
 
         if forced is not None:
             feed(0)
-        splits = self.attn_splits or (1 if R * c.kv_heads >= 160 else max(2, min(16, 768 // max(1, R * c.kv_heads))))
+        splits = self.attn_splits or pick_attn_splits(R, c.kv_heads)
         steps = max_new - 1
         if use_graph and not return_logits and forced is None and steps > 0:
-            key = (R, splits, max_new, min_new, rp)
+            key = (R, splits, max_new, min_new, rp, tuple(c.eos_ids), c.pad_id)
             if key not in self._graphs:
                 # one eager step first: lazy one-time kernel attributes must not be set inside a capture
                 _lib.check(lib.hwocr_decode_step(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs), R, splits, st))
@@ -801,11 +868,12 @@ class ReadEngine:
                 self._gs_keep = (gs, eos)
                 _lib.check(lib.hwocr_decode_graph_create(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs), R,
                                                          splits, C.byref(g)), "hwocr_decode_graph_create")
-                self._graphs[key] = g
+                self._remember_graph(key, g)
+            graph = self._use_graph(key)
             done = 0
             while done < steps:
                 n = min(32, steps - done)
-                _lib.check(lib.hwocr_decode_graph_launch(self._graphs[key], n, st), "hwocr_decode_graph_launch")
+                _lib.check(lib.hwocr_decode_graph_launch(graph, n, st), "hwocr_decode_graph_launch")
                 done += n
                 if min_new < max_new and bool(self.finished[:R].all()):
                     break
@@ -818,6 +886,7 @@ class ReadEngine:
                     feed(i + 1)
         mark("decode")
         torch.cuda.current_stream().synchronize()
+        self._check_status()
         if marks:
             self.timings = {marks[i][0] + "_ms": marks[i - 1][1].elapsed_time(marks[i][1]) for i in range(1, len(marks))}
             self.timings["decode_steps"] = max_new - 1
@@ -867,7 +936,8 @@ class ReadEngine:
                            finished=_lib.ptr(self.finished), out_tokens=_lib.ptr(self.out_tokens),
                            rope_delta=_lib.ptr(self.rope_delta), max_new=max_new, min_new=min_new,
                            n_eos=min(len(c.eos_ids), 4), pad_id=c.pad_id, eos=eos,
-                           seen=_lib.ptr(self._seen) if rp != 1.0 else None, seen_ld=seen_ld, rep_penalty=rp)
+                           seen=_lib.ptr(self._seen) if rp != 1.0 else None, seen_ld=seen_ld, rep_penalty=rp,
+                           status=_lib.ptr(self.status))
         # idle slots decode a finished one-token read (cheap) until a real read moves in
         self.finished[:R].fill_(1)
         self.lens[:R].fill_(1)
@@ -877,7 +947,7 @@ class ReadEngine:
         slot_read = [-1] * R
         results: list = [None] * N
         nxt = 0
-        splits = self.attn_splits or (1 if R * c.kv_heads >= 160 else max(2, min(16, 768 // max(1, R * c.kv_heads))))
+        splits = self.attn_splits or pick_attn_splits(R, c.kv_heads)
         ws = self._dec_ws(max(min(self.prefill_batch, R) * _ceil(Tmax, 64), self.max_reads))
 
         def admit(slots: list[int]) -> None:
@@ -935,7 +1005,7 @@ class ReadEngine:
             for s, r in zip(slots, reads):
                 slot_read[s] = r
 
-        key = (R, splits, max_new, min_new, rp)
+        key = (R, splits, max_new, min_new, rp, tuple(c.eos_ids), c.pad_id)
         while True:
             free = [s for s in range(R) if slot_read[s] < 0]
             if free and nxt < N and (len(free) >= (min_admit or max(1, R // 8)) or len(free) == R or N - nxt <= len(free)):
@@ -949,11 +1019,12 @@ class ReadEngine:
                 self._gs_keep = (gs, eos)
                 _lib.check(lib.hwocr_decode_graph_create(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs), R, splits,
                                                          C.byref(g)), "hwocr_decode_graph_create")
-                self._graphs[key] = g
+                self._remember_graph(key, g)
                 _lib.check(lib.hwocr_decode_graph_launch(g, sync_every - 1, st), "hwocr_decode_graph_launch")
             else:
-                _lib.check(lib.hwocr_decode_graph_launch(self._graphs[key], sync_every, st), "hwocr_decode_graph_launch")
+                _lib.check(lib.hwocr_decode_graph_launch(self._use_graph(key), sync_every, st), "hwocr_decode_graph_launch")
             torch.cuda.current_stream().synchronize()
+            self._check_status()
             fin = self.finished[:R].cpu().numpy()
             ng = self.n_gen[:R].cpu().numpy()
             done = [s for s in range(R) if slot_read[s] >= 0 and (fin[s] or ng[s] >= max_new)]

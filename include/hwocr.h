@@ -38,7 +38,7 @@ typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
 #define HWOCR_EPI_GELU_TANH 6 /* nn.GELU(approximate="tanh"): SigLIP MLP (HF siglip/modeling_siglip.py:310-322) */
 #define HWOCR_EPI_GEGLU 7     /* SWIGLU's interleaved tile pairs with the tanh GELU as gate: Gemma MLP (HF gemma/modeling_gemma.py:84-97) */
 
-#define HWOCR_ABI_VERSION 6 /* bumped whenever a signature or struct layout below changes */
+#define HWOCR_ABI_VERSION 7 /* bumped whenever a signature or struct layout below changes */
 int hwocr_abi_version(void);
 /* text of the most recent launch failure in this process ("" if none): launcher name + HIP error */
 const char* hwocr_last_error(void);
@@ -71,6 +71,12 @@ int hwocr_gemm_wide_fp8(const void* X8, const float* xscale, const void* W8, con
 int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out, int Bsz, int N, int K, int ldx,
                       int ldw, int ldo, int epi, int splitk, int w_tiled, hwocr_stream_t stream);
 
+/* Name of the kernel instance the call hwocr_gemm_skinny(Bsz, N, K, epi, splitk, w_tiled) would launch (ldx = ldw = K,
+ * ldo = N), written NUL-terminated into name[name_len]; launches nothing and needs no device.  The decode GEMMs pick among
+ * several instances by shape (csrc/gemm_stream.hip plan_stream): the parity tests use this to prove that every instance a
+ * shipped configuration dispatches has an oracle case. */
+int hwocr_gemm_skinny_variant(int Bsz, int N, int K, int epi, int splitk, int w_tiled, char* name, int name_len);
+
 /* [N][K] row-major weights -> [N/16][K/32][64 lanes][8] (lane = 16*((k/8)%4) + n%16): the order in which one wave's
  * MFMA A fragments are consumed, so decode streams every weight byte as contiguous KiB blocks.  N%16 == 0, K%32 == 0. */
 int hwocr_tile_weights(const void* src, void* dst, int N, int K, int ldw, hwocr_stream_t stream);
@@ -92,10 +98,13 @@ int hwocr_attn_varlen(const void* Q, const void* K, const void* VT, void* O, con
 
 /* One query token per read against its KV cache (HF modeling_qwen2_vl.py:553-569 with q_len == 1).  head_dim 128, or 256
  * (Gemma) with the row layout only.  kv_tiled (here and in the cache writers below): the cache is in the fragment-tiled
- * layout, strides k_row/v_row unused. */
+ * layout, strides k_row/v_row unused.  1 <= nsplit <= 16 (part_o / part_ml hold 16 splits). */
 int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out, float* part_o,
                       float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head, long v_seq,
                       long v_head, long v_row, float scale, int head_dim, int kv_tiled, hwocr_stream_t stream);
+
+/* as hwocr_gemm_skinny_variant, for hwocr_attn_decode */
+int hwocr_attn_decode_variant(int nsplit, int head_dim, int kv_tiled, char* name, int name_len);
 
 /* uint8 HWC resized pages -> bf16 patch rows (HF image_processing_pil_qwen2_vl.py:152-187, :226-229).
  * row_src (optional, device int32 [gh*gw]): output row r of every image shows patch row_src[r] of the processor's
@@ -123,10 +132,16 @@ int hwocr_mrope_kv_prefill(const void* qkv, void* Q, void* K, void* VT, const in
                            long k_seq, long k_head, long v_seq, long v_head, long v_row, int head_dim, int kv_tiled,
                            hwocr_stream_t stream);
 
+/* Decode form: one row per read = the split-K slabs of the fused QKV projection (+ bias); rotary at position
+ * lens - 1 + rope_delta, K / V^T appended at cache slot lens - 1.  The caller keeps 1 <= lens <= ctx and
+ * 0 <= lens - 1 + rope_delta < max_pos (rows of the rope tables); a read that breaks this is skipped (nothing written,
+ * nothing read outside the tables) and HWOCR_STATUS_BAD_POSITION is OR-ed into *status (device int, may be NULL). */
+#define HWOCR_STATUS_BAD_POSITION 1
 int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_stride, const void* bias, void* Q, void* K,
                             void* VT, const int* lens, const int* rope_delta, const void* cos_tab,
                             const void* sin_tab, int nseq, int Hq, int Hkv, long k_seq, long k_head, long v_seq,
-                            long v_head, long v_row, int head_dim, int kv_tiled, hwocr_stream_t stream);
+                            long v_head, long v_row, int head_dim, int kv_tiled, int ctx, int max_pos, int* status,
+                            hwocr_stream_t stream);
 
 int hwocr_embed_splice(const int* ids, const int* img_row, const void* table, const void* img, void* out, int rows,
                        int D, float scale, hwocr_stream_t stream);
@@ -207,7 +222,8 @@ typedef struct {
   const void* lm_head_t;    /* fragment-tiled copy of lm_head for decode (may be NULL) */
   const void* final_norm_w;
   const hwocr_dec_layer* L; /* host array[layers] */
-  const void *rope_cos, *rope_sin; /* bf16 [maxpos][64] */
+  const void *rope_cos, *rope_sin; /* bf16 [max_pos][head_dim/2] */
+  int max_pos;                     /* rows of the rope tables */
 } hwocr_decoder;
 
 typedef struct { /* KV cache: K [layer][seq][Hkv][ctx][128], VT [layer][seq][Hkv][128][ctx]; tiled != 0: every
@@ -231,6 +247,8 @@ typedef struct {
   unsigned* seen; /* repetition-penalty bitmap [reads][seen_ld] (see hwocr_argmax_advance) or NULL */
   int seen_ld;
   float rep_penalty;
+  int* status; /* device int32 (or NULL): HWOCR_STATUS_* bits raised by decode steps that met a read outside its invariants;
+                * the host reads it whenever it synchronises and treats non-zero as an error */
 } hwocr_gen_state;
 
 /* prefill nseq reads laid out [nseq][rows_per_seq]; writes KV for reads seq0.. and the first generated token */
@@ -241,6 +259,11 @@ int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv
 /* one greedy token for every read in flight (reads 0..nseq-1 of the cache) */
 int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv, const hwocr_gen_state* st,
                       int nseq, int attn_splits, hwocr_stream_t stream);
+
+/* The GEMM calls one hwocr_decode_step makes (layer 0; every layer has the same shapes), as arguments of hwocr_gemm_skinny:
+ * which = 0 qkv, 1 o, 2 gate/up, 3 down, 4 LM head.  Only m's dimensions and the NULL-ness of the tiled weight pointers of
+ * m->L[0] / m->lm_head_t are read.  Launches nothing. */
+int hwocr_decode_gemm_plan(const hwocr_decoder* m, int nseq, int which, int* N, int* K, int* epi, int* splitk, int* w_tiled);
 
 /* capture one decode step into a HIP graph; replay it n times back-to-back on `stream` */
 int hwocr_decode_graph_create(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,

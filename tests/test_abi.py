@@ -33,6 +33,26 @@ def test_abi_version_and_structs():
     with open(os.path.join(ROOT, "include", "hwocr.h")) as f:
         declared = int(re.search(r"#define HWOCR_ABI_VERSION (\d+)", f.read()).group(1))
     assert _lib.hip().hwocr_abi_version() == declared == _lib.ABI_VERSION
-    # layout contract with include/hwocr.h (LP64): ints, one float, then 8-byte-aligned pointers
-    assert C.sizeof(_lib.Vit) == 48 + 13 * 8 and C.sizeof(_lib.VitBlock) == 21 * 8 and C.sizeof(_lib.VitLayout) == 7 * 8 and C.sizeof(_lib.Decoder) == 48 + 7 * 8 and C.sizeof(_lib.DecLayer) == 19 * 8
-    assert C.sizeof(_lib.GenState) == 6 * 8 + 8 * 4 + 8 + 2 * 4 and C.sizeof(_lib.Kv) == 32
+    # layout contract with include/hwocr.h: sizes and field offsets as gcc lays the structs out, against the ctypes mirrors
+    import subprocess
+    import tempfile
+
+    pairs = {"hwocr_vit": _lib.Vit, "hwocr_vit_block": _lib.VitBlock, "hwocr_vit_layout": _lib.VitLayout,
+             "hwocr_vit_ws": _lib.VitWs, "hwocr_decoder": _lib.Decoder, "hwocr_dec_layer": _lib.DecLayer,
+             "hwocr_gen_state": _lib.GenState, "hwocr_kv": _lib.Kv, "hwocr_dec_ws": _lib.DecWs, "hwocr_w8": _lib.W8}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hwocr.h"', "int main(void) {"]
+    for cname, ct in pairs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "abi.c"), os.path.join(d, "abi")
+        with open(src, "w") as f:
+            f.write("\n".join(lines))
+        subprocess.run(["gcc", "-I" + os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        got = dict(l.split() for l in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, ct in pairs.items():
+        assert int(got[cname]) == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"

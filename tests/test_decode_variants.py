@@ -1,0 +1,73 @@
+"""Every kernel instance a shipped configuration's decode step dispatches must have an oracle case.
+
+The decode GEMM launcher picks a kernel instance from the shape (csrc/gemm_stream.hip plan_stream; csrc/gemm.hip
+skinny_takes_stream) and so does the decode attention.  This test asks the library's own planner — no launch, no GPU —
+which instance every preset runs at the read counts the bench uses, and checks it against the instances reached by the
+parity cases of tests/test_ops_gpu.py (which run on the MI355X against the fp32 product of the same operands)."""
+import ctypes as C
+
+import pytest
+
+from handwritten_ocr_amd import _lib, engine
+from tests import test_ops_gpu as ops
+
+PRESETS = ("qwen2-vl-2b", "qwen2.5-vl-7b", "qwen2.5-vl-3b", "paligemma-3b", "small", "tiny", "tiny25", "tinypg")
+READS = (1, 3, 126, 252)
+
+
+def _gemm_variant(B, N, K, epi, splitk):
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.hip().hwocr_gemm_skinny_variant(B, N, K, epi, splitk, 1, buf, len(buf)))
+    return buf.value.decode()
+
+
+def _attn_variant(nsplit, hd, tiled):
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.hip().hwocr_attn_decode_variant(nsplit, hd, tiled, buf, len(buf)))
+    return buf.value.decode()
+
+
+def _covered():
+    gemm = {_gemm_variant(*c) for c in ops.DECODE_GEMM_CASES}
+    # the older operator cases: (B, N, K) x {linear, partial} and the gated ones at N = 3584
+    for B in (1, 7, 16, 48, 96, 128, 190, 256):
+        for N, K in ((96, 64), (2048, 1536), (1536, 2304)):
+            gemm.add(_gemm_variant(B, N, K, 0, 1))
+            gemm.add(_gemm_variant(B, N, K, 5, 1))
+    for B in (3, 48, 96, 252):
+        gemm |= {_gemm_variant(B, 3584, 1536, 4, 1), _gemm_variant(B, 3584, 1536, 7, 1)}
+    attn = {_attn_variant(ns, hd, tiled) for (_, _, _, hd, tiled, _, ns) in ops.ATTN_DECODE_BENCH_CASES}
+    attn |= {_attn_variant(ns, hd, tiled) for ns in (1, 4) for hd, tiled in ((128, 0), (128, 1), (256, 0))}
+    return gemm, attn
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+def test_every_dispatched_decode_kernel_has_an_oracle_case(preset):
+    gemm, attn = _covered()
+    cfg = engine.preset(preset)
+    missing = []
+    for reads in READS:
+        plan = engine.decode_plan(cfg, reads)
+        for name in engine.DECODE_GEMMS:
+            if plan[name][4] not in gemm:
+                missing.append((reads, name) + plan[name])
+        if plan["attn"] not in attn:
+            missing.append((reads, "attn", plan["attn"]))
+    assert not missing, f"{preset}: decode kernels without a parity case: {missing}"
+
+
+def test_bench_default_shapes_are_literal_cases():
+    """`python bench.py` = Qwen2-VL-2B at 252 reads: its five GEMMs must be among the cases shape for shape."""
+    plan = engine.decode_plan(engine.preset("qwen2-vl-2b"), 252)
+    for name in engine.DECODE_GEMMS:
+        N, K, epi, splitk, _ = plan[name]
+        assert (N, K, epi, splitk) in ops.DECODE_GEMM_SHAPES[252], (name, plan[name])
+
+
+def test_variant_query_rejects_what_the_launcher_rejects():
+    buf = C.create_string_buffer(64)
+    lib = _lib.hip()
+    assert lib.hwocr_gemm_skinny_variant(257, 2048, 1536, 0, 1, 1, buf, len(buf)) == 1   # > 256 rows
+    assert lib.hwocr_gemm_skinny_variant(8, 2048, 1536, 0, 2, 1, buf, len(buf)) == 1     # split-K without PARTIAL
+    assert lib.hwocr_attn_decode_variant(17, 128, 1, buf, len(buf)) == 1
+    assert lib.hwocr_attn_decode_variant(1, 256, 1, buf, len(buf)) == 1                  # tiled cache is head_dim 128 only

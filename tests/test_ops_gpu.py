@@ -158,6 +158,60 @@ def test_gemm_skinny_swiglu(B, tiled):
                           what=f"skinny glu epi={epi}")
 
 
+# The decode-step GEMMs exactly as hwocr_decode_step issues them for the shipped presets at the bench's read counts
+# (126 = the pre-r01g default, 252 = `python bench.py`): (N, K, epi, splitk) from engine.decode_plan — qkv / o / gate-up /
+# down / LM head of Qwen2-VL-2B, Qwen2.5-VL-7B (olmOCR-2), Qwen2.5-VL-3B, PaliGemma-3B (GeGLU) and the `small` preset.
+# tests/test_decode_variants.py (CPU) walks every preset x read count through the library's launch planner and fails if a
+# kernel instance it picks has no case here.
+DECODE_GEMM_SHAPES = {
+    126: [(2048, 1536, 5, 4), (1536, 1536, 5, 4), (17920, 1536, 4, 1), (1536, 8960, 5, 12), (151936, 1536, 0, 1),
+          (4608, 3584, 5, 8), (3584, 3584, 5, 8), (37888, 3584, 4, 1), (3584, 18944, 5, 12), (152064, 3584, 0, 1),
+          (2560, 2048, 5, 5), (2048, 2048, 5, 5), (22016, 2048, 4, 1), (2048, 11008, 5, 12), (151936, 2048, 0, 1),
+          (32768, 2048, 7, 1), (2048, 16384, 5, 12), (257216, 2048, 0, 1),
+          (1280, 768, 5, 2), (768, 768, 5, 2), (6144, 768, 4, 1), (768, 3072, 5, 8), (32768, 768, 0, 1)],
+    252: [(2048, 1536, 5, 4), (1536, 1536, 5, 4), (17920, 1536, 4, 1), (1536, 8960, 5, 8), (151936, 1536, 0, 1),
+          (4608, 3584, 5, 4), (3584, 3584, 5, 4), (37888, 3584, 4, 1), (3584, 18944, 5, 8), (152064, 3584, 0, 1),
+          (2560, 2048, 5, 4), (2048, 2048, 5, 4), (22016, 2048, 4, 1), (2048, 11008, 5, 8), (151936, 2048, 0, 1),
+          (32768, 2048, 7, 1), (2048, 16384, 5, 8), (257216, 2048, 0, 1),
+          (1280, 768, 5, 2), (768, 768, 5, 2), (6144, 768, 4, 1), (768, 3072, 5, 8), (32768, 768, 0, 1)],
+    # one page = 3 reads in flight (BASELINE config 2 as literally stated), and the 129..256-row kernels away from 252
+    3: [(2048, 1536, 5, 4), (17920, 1536, 4, 1), (1536, 8960, 5, 12), (151936, 1536, 0, 1), (32768, 2048, 7, 1)],
+    130: [(2048, 1536, 5, 4), (17920, 1536, 4, 1), (1536, 8960, 5, 8), (151936, 1536, 0, 1), (37888, 3584, 4, 1)],
+    256: [(17920, 1536, 4, 1), (1536, 8960, 5, 8), (151936, 1536, 0, 1), (32768, 2048, 7, 1)],
+}
+DECODE_GEMM_CASES = [(B,) + shape for B, shapes in DECODE_GEMM_SHAPES.items() for shape in shapes]
+
+
+@pytest.mark.parametrize("B,N,K,epi,splitk", DECODE_GEMM_CASES)
+def test_gemm_skinny_decode_shapes(B, N, K, epi, splitk):
+    """hwocr_gemm_skinny(tiled weights) on the shapes, epilogues and split-K the decode step uses, at its row counts,
+    against the fp32 product of the same bf16 operands (what HF's nn.Linear + SiLU/GELU-gated MLP compute:
+    modeling_qwen2_vl.py:453-466, :501-504; gemma/modeling_gemma.py:84-97)."""
+    x = randbf(B, K, seed=70)
+    w = randbf(N, K, scale=K ** -0.5, seed=71)
+    wk = _tiled(w)
+    acc = x.float() @ w.float().t()
+    if epi == 5:
+        slabs = torch.full((splitk, B, N), float("nan"), dtype=torch.float32, device=DEV)
+        assert lib().hwocr_gemm_skinny(p(x), p(wk), None, p(slabs), B, N, K, K, K, N, 5, splitk, 1, st()) == 0
+        sync()
+        got = slabs.sum(0)
+        assert torch.isfinite(got).all(), "a slab element was left unwritten"
+        assert torch.allclose(got, acc, rtol=1e-4, atol=2e-3), f"partial splitk={splitk}: {(got - acc).abs().max()}"
+    elif epi == 0:
+        out = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        assert lib().hwocr_gemm_skinny(p(x), p(wk), None, p(out), B, N, K, K, K, N, 0, 1, 1, st()) == 0
+        sync()
+        assert_close_bf16(out, acc, ulps=2.0, atol=2e-3, what="decode linear (LM head)")
+    else:
+        out = torch.full((B, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+        assert lib().hwocr_gemm_skinny(p(x), p(wk), None, p(out), B, N, K, K, K, N // 2, epi, 1, 1, st()) == 0
+        sync()
+        want = _swiglu_ref(acc, geglu=(epi == 7))
+        gate = rbf(acc.view(B, N // 32, 2, 16)[:, :, 0, :]).reshape(B, N // 2)
+        assert_close_bf16(out, want, ulps=3.0, atol=2e-3, what=f"decode glu epi={epi}", mag=want.abs() * (1.0 + gate.abs()))
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _sdpa_ref(q, k, v, causal, scale):
     # q [Hq, L, d], k/v [Hkv, L, d] (fp32); returns [L, Hq, d]
@@ -287,6 +341,51 @@ def test_attn_decode(nsplit, hd, Hq, Hkv, tiled):
         qq = q[b].float().unsqueeze(1)  # [Hq,1,d]
         want = _sdpa_ref(qq, k[b, :, :n].float(), v[b, :, :n].float(), False, hd ** -0.5).reshape(Hq * hd)
         assert_close_bf16(out[b], want, ulps=4.0, atol=4e-3, what=f"attn_decode read {b} len {n}")
+
+
+# (B, Hq, Hkv, hd, tiled, ctx, nsplit): the decode attention as the bench runs it — 252 / 126 reads x 2048 cached positions,
+# lengths spread over the 512 generated tokens past the 1328-token prompt (Qwen2-VL-2B, Qwen2.5-VL-7B head counts; the row
+# layout with 256-wide heads for Gemma at 126 reads = 4 splits + merge and at 252 = one pass)
+ATTN_DECODE_BENCH_CASES = [(252, 12, 2, 128, 1, 2048, 1), (126, 12, 2, 128, 1, 2048, 1), (252, 28, 4, 128, 1, 2048, 1),
+                           (3, 12, 2, 128, 1, 2048, 16), (126, 8, 1, 256, 0, 1280, 6), (252, 8, 1, 256, 0, 1280, 1)]
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,hd,tiled,ctx,nsplit", ATTN_DECODE_BENCH_CASES)
+def test_attn_decode_bench_shapes(B, Hq, Hkv, hd, tiled, ctx, nsplit):
+    g = torch.Generator().manual_seed(5)
+    lo = ctx * 1328 // 2048
+    lens = torch.randint(lo, ctx - 200, (B,), generator=g).tolist()
+    lens[0], lens[-1] = lo, ctx  # the shortest and the full cache
+    q = randbf(B, Hq, hd, seed=15)
+    k = randbf(B, Hkv, ctx, hd, seed=16)
+    v = randbf(B, Hkv, ctx, hd, seed=17)
+    vt = v.transpose(2, 3).contiguous()
+    for b, n in enumerate(lens):
+        vt[b, :, :, n:] = float("nan")
+        k[b, :, n:, :] = 1e4
+    out = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    G = Hq // Hkv
+    part_o = torch.zeros(B * Hkv * nsplit * G * hd, dtype=torch.float32, device=DEV)
+    part_ml = torch.zeros(B * Hkv * nsplit * G * 2, dtype=torch.float32, device=DEV)
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    kk, vv = (tile_k(k), tile_v(vt)) if tiled else (k, vt)
+    rc = lib().hwocr_attn_decode(p(q), p(kk), p(vv), p(lens_d), p(out), p(part_o), p(part_ml), B, Hq, Hkv, nsplit,
+                                 Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, hd, tiled, st())
+    assert rc == 0
+    sync()
+    # fp32 reference of all reads at once: scores masked past each read's length
+    kf, vf = k.float().repeat_interleave(G, 1), v.float().repeat_interleave(G, 1)
+    s = torch.einsum("bhd,bhkd->bhk", q.float(), kf) * hd ** -0.5
+    mask = torch.arange(ctx, device=DEV)[None, None, :] >= lens_d[:, None, None]
+    pr = torch.softmax(s.masked_fill(mask, float("-inf")), -1)
+    want = torch.einsum("bhk,bhkd->bhd", pr, torch.nan_to_num(vf)).reshape(B, Hq * hd)
+    assert_close_bf16(out, want, ulps=4.0, atol=4e-3, what="attn_decode at the bench's size")
+
+
+def test_attn_decode_rejects_more_than_16_splits():
+    q = randbf(1, 2, 128)
+    assert lib().hwocr_attn_decode(p(q), p(q), p(q), p(q), p(q), p(q), p(q), 1, 2, 1, 17, 128 * 64, 128 * 64, 128 * 64,
+                                   128 * 64, 64, 1.0, 128, 0, st()) == 1
 
 
 # ------------------------------------------------------------------------------------------------ row-wise kernels
@@ -476,11 +575,14 @@ def test_decode_qkv_finish(hd, Hq, Hkv, sec0, sec1, tiled):
     Kc = torch.zeros(B, Hkv, ctx, hd, dtype=torch.bfloat16, device=DEV)
     VT = torch.zeros(B, Hkv, hd, ctx, dtype=torch.bfloat16, device=DEV)
     lens_d, delta_d, cos_d, sin_d = lens.to(DEV), delta.to(DEV), cos_t.to(DEV), sin_t.to(DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
     rc = lib().hwocr_decode_qkv_finish(p(slabs), nslab, B * W, p(bias), p(Q), p(Kc), p(VT), p(lens_d),
                                        p(delta_d), p(cos_d), p(sin_d), B, Hq, Hkv,
-                                       Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd, tiled, st())
+                                       Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd, tiled, ctx, 512,
+                                       p(status), st())
     assert rc == 0
     sync()
+    assert int(status) == 0
     if tiled:
         Kc, VT = untile_k(Kc), untile_v(VT)
     row = rbf((slabs.sum(0) + bias.float()).cpu())
@@ -496,6 +598,45 @@ def test_decode_qkv_finish(hd, Hq, Hkv, sec0, sec1, tiled):
         assert_close_bf16(VT[b, :, :, slot].cpu(), row[b, (Hq + Hkv) * hd:].view(Hkv, hd), ulps=1.0, atol=1e-3,
                           what="decode v")
         assert (Kc[b].float().abs().sum(-1) != 0).sum() == Hkv  # exactly one slot written per kv head
+
+
+@pytest.mark.parametrize("tiled", [0, 1])
+def test_decode_qkv_finish_flags_reads_outside_their_invariants(tiled):
+    """A read whose position lens - 1 + rope_delta falls before / past the rope table, or whose cache slot is outside the
+    cache (a parked slot that kept the negative rope_delta of the read it held; a length that ran past ctx), is skipped —
+    nothing of it is written — and HWOCR_STATUS_BAD_POSITION is raised; the healthy reads of the same launch are served.
+    Round 1 clamped the position to 0 instead, which hid exactly this host bug (commit 7665a5c)."""
+    hd, Hq, Hkv, B, ctx, nslab, max_pos = 128, 4, 2, 6, 128, 2, 160
+    W = (Hq + 2 * Hkv) * hd
+    slabs = torch.randn(nslab, B, W, device=DEV)
+    #          ok   parked, stale -1295   ok    slot past ctx   position past the table   lens 0
+    lens = [10, 1, 128, 129, 100, 0]
+    delta = [-3, -1295, 31, 0, 80, 0]
+    bad = [False, True, False, True, True, True]
+    cos_t, sin_t = _rope_tables(max_pos, hd=hd)
+    Q = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    Kc = torch.zeros(B, Hkv, ctx, hd, dtype=torch.bfloat16, device=DEV)
+    VT = torch.zeros(B, Hkv, hd, ctx, dtype=torch.bfloat16, device=DEV)
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    delta_d = torch.tensor(delta, dtype=torch.int32, device=DEV)
+    cos_d, sin_d = cos_t.to(DEV), sin_t.to(DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    rc = lib().hwocr_decode_qkv_finish(p(slabs), nslab, B * W, None, p(Q), p(Kc), p(VT), p(lens_d), p(delta_d), p(cos_d),
+                                       p(sin_d), B, Hq, Hkv, Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd, tiled,
+                                       ctx, max_pos, p(status), st())
+    assert rc == 0
+    sync()
+    assert int(status) == 1
+    for b in range(B):
+        touched = bool(Q[b].float().abs().sum() != 0) or bool(Kc[b].float().abs().sum() != 0) or bool(VT[b].float().abs().sum() != 0)
+        assert touched != bad[b], f"read {b}: lens {lens[b]} delta {delta[b]}"
+    # without a status word the bad reads are still skipped
+    Q.zero_()
+    assert lib().hwocr_decode_qkv_finish(p(slabs), nslab, B * W, None, p(Q), p(Kc), p(VT), p(lens_d), p(delta_d), p(cos_d),
+                                         p(sin_d), B, Hq, Hkv, Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd,
+                                         tiled, ctx, max_pos, None, st()) == 0
+    sync()
+    assert all(bool(Q[b].float().abs().sum() != 0) != bad[b] for b in range(B))
 
 
 def test_embed_splice():
