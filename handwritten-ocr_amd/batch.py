@@ -16,8 +16,11 @@ With agents, every DISTINCT preprocessing strategy of every page is read in the 
 `reocr` node (nodes.py:239-302: next unused strategy, one more read, after a model reload in the reference) is then
 answered from that pass — same node code, same text, no second trip through the engine.
 
-Multi-GPU: one process per GPU (`torchrun`), pages dealt round-robin (`shard.shard`), every rank writes its own pages'
-files; token streams are additionally gathered to rank 0 by `tools.run_ocr_batch` callers that need them (bench.py).
+Multi-GPU: one process per GPU (`torchrun`, or any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE), the
+sorted page list dealt round-robin (`shard.shard`), all reads of a page on one GPU; every rank runs only the engine pass over
+its pages, the generated token streams are gathered to rank 0 over RCCL (`shard.gather_token_streams`, a few KB per read), and
+rank 0 alone detokenises, replays the nodes, runs the agents and writes every page's files — the reference's loop
+(transcribe.py:185-210) with its engine work spread over the node.
 
 CLI:  python -m handwritten_ocr_amd.batch <folder-or-image> [--output-dir D] [--ground-truth-dir G] [--max-new-tokens N]
 """
@@ -87,16 +90,19 @@ def _replay_readers(strategies: list, texts: list, fallback=None):
     return replay_preprocess, replay_run_ocr
 
 
-def initial_ocr_batched(image_paths: list, params: dict | None = None, cfg=config, workers: int = 8,
-                        speculate_reocr: bool = False, reads_out: list | None = None) -> list[dict]:
-    """States after `initial_ocr` for every page, computed with ONE batched engine pass over all reads.
-    `speculate_reocr`: also read the strategies a later `reocr` node would use; `reads_out` (a list) receives, per page,
-    (strategies, texts) of everything that was read."""
+def read_pages(image_paths: list, params: dict | None = None, cfg=config, workers: int = 8,
+               speculate_reocr: bool = False) -> tuple[list, list]:
+    """ONE batched engine pass over every strategy read of `image_paths`: (strategies, streams) with streams[p][k] = the
+    generated token ids of page p under strategies[k].  `speculate_reocr`: also read the strategies a later `reocr` node
+    would use."""
     strategies = _speculative_strategies(list(cfg.PREPROCESSING_STRATEGIES), every=speculate_reocr)
+    if not image_paths:
+        return strategies, []
 
     # HWOCR_GPU_PREPROCESS=1 (SURVEY 8f-3): the strategy chains and the processor's resize run on the device, bit-identical
-    # to the host path (gpupre.py); a page is decoded and uploaded once for all its reads.  Pages that are not plain RGB and
-    # chains the device path does not cover (OpenCV present, a transform after binarize) keep the host path.
+    # to the host path (gpupre.py); a page is decoded and uploaded once for all its reads.  Pages that are not plain RGB,
+    # chains the device path does not cover (OpenCV present, a transform after binarize) and pages whose file format
+    # re-quantises on save (below) keep the host path.
     gpu_pages = None
     if os.environ.get("HWOCR_GPU_PREPROCESS", "0") not in ("", "0"):
         from . import gpupre
@@ -108,9 +114,20 @@ def initial_ocr_batched(image_paths: list, params: dict | None = None, cfg=confi
     def prepare(path):
         img = Image.open(path)
         img.load()
-        if gpu_pages is not None and img.mode == "RGB":
+        suffix = Path(path).suffix.lower()
+        lossy = suffix in preprocess.LOSSY_SUFFIXES
+        if gpu_pages is not None and img.mode == "RGB" and not lossy:
             return np.asarray(img)
-        return [preprocess.apply_strategy(img, s, quiet=True) for s in strategies]
+        # The serial path hands every transformed page to the model through a temp file with the INPUT's suffix
+        # (tools.py:668-672): for .jpg / .jpeg / .webp that re-encode changes the pixels, so it is reproduced here (in
+        # memory); "original" reads the input file itself (tools.py:651-652) and is not re-encoded.
+        out = []
+        for s in strategies:
+            pre = preprocess.apply_strategy(img, s, quiet=True)
+            if lossy and preprocess.steps_of(s) not in (["original"], []):
+                pre = preprocess.through_tempfile_codec(pre, suffix)
+            out.append(pre)
+        return out
 
     with ThreadPoolExecutor(max_workers=workers) as pool:
         prepared = list(pool.map(prepare, image_paths))
@@ -119,14 +136,17 @@ def initial_ocr_batched(image_paths: list, params: dict | None = None, cfg=confi
         prepared = [sp.pages(p, strategies, processor.target_hw(p.shape[0], p.shape[1])) if isinstance(p, np.ndarray) else p
                     for p in prepared]
     flat = [im for page in prepared for im in page]
-    texts = tools.run_ocr_batch(flat, params)
-    states = []
+    toks = tools.run_ocr_batch_tokens(flat, params)
     k = len(strategies)
-    for p, path in enumerate(image_paths):
-        page_texts = texts[p * k: (p + 1) * k]
+    return strategies, [toks[p * k: (p + 1) * k] for p in range(len(image_paths))]
+
+
+def replay_initial_ocr(image_paths: list, strategies: list, texts: list, cfg=config) -> list[dict]:
+    """States after `initial_ocr` for every page: the reference's node code run per page with `preprocess_image` /
+    `run_ocr` answering from the finished batch (texts[p][k] = page p under strategies[k])."""
+    states = []
+    for path, page_texts in zip(image_paths, texts):
         fake_preprocess, fake_run_ocr = _replay_readers(strategies, page_texts)
-        if reads_out is not None:
-            reads_out.append((strategies, page_texts))
         state = new_state(str(path), cfg)
         saved = (nodes.preprocess_image, nodes.run_ocr, nodes.unload_ocr_model)
         nodes.preprocess_image, nodes.run_ocr, nodes.unload_ocr_model = fake_preprocess, fake_run_ocr, (lambda: None)
@@ -136,6 +156,48 @@ def initial_ocr_batched(image_paths: list, params: dict | None = None, cfg=confi
             nodes.preprocess_image, nodes.run_ocr, nodes.unload_ocr_model = saved
         states.append(state)
     return states
+
+
+def initial_ocr_batched(image_paths: list, params: dict | None = None, cfg=config, workers: int = 8,
+                        speculate_reocr: bool = False, reads_out: list | None = None) -> list[dict]:
+    """States after `initial_ocr` for every page, computed with ONE batched engine pass over all reads (single process).
+    `reads_out` (a list) receives, per page, (strategies, texts) of everything that was read."""
+    strategies, streams = read_pages(image_paths, params, cfg, workers, speculate_reocr)
+    flat = tools.decode_tokens([t for page in streams for t in page])
+    k = len(strategies)
+    texts = [flat[p * k: (p + 1) * k] for p in range(len(image_paths))]
+    if reads_out is not None:
+        reads_out.extend((strategies, t) for t in texts)
+    return replay_initial_ocr(image_paths, strategies, texts, cfg)
+
+
+def gather_reads(streams: list, n_pages_total: int, k: int) -> list | None:
+    """Every rank's streams[p][k] (pages dealt round-robin, k reads per page) -> on rank 0 the streams of ALL pages in the global page order;
+    None elsewhere.  One padded fixed-shape gather (shard.gather_token_streams): RCCL on the GPUs, gloo in the CPU tests."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return streams
+    world = dist.get_world_size()
+    dev = torch.device(f"cuda:{torch.cuda.current_device()}") if dist.get_backend() == "nccl" else torch.device("cpu")
+    flat = [t for page in streams for t in page]
+    width = max([len(t) for t in flat] + [1])
+    toks = torch.zeros(len(flat), width, dtype=torch.int32)
+    for i, t in enumerate(flat):
+        toks[i, : len(t)] = torch.tensor(t, dtype=torch.int32)
+    counts = torch.tensor([len(t) for t in flat], dtype=torch.int32)
+    got = shard.gather_token_streams(toks.to(dev), counts.to(dev), dst=0)
+    if got is None:
+        return None
+    per_rank = []
+    for t, c in got:
+        t, c = t.cpu().tolist(), c.cpu().tolist()
+        per_rank.append([row[:n] for row, n in zip(t, c)])
+    out = []
+    for r, j in shard.owner_index(n_pages_total, world):
+        out.append(per_rank[r][j * k: (j + 1) * k])
+    return out
 
 
 def _fmt_elapsed(seconds: float) -> str:
@@ -166,15 +228,25 @@ def write_outputs(state: dict, output_dir: Path, ground_truth_path: Path | None 
 
 def transcribe_folder(images: list, output_dir: Path, ground_truth_dir: Path | None = None, params: dict | None = None,
                       agents: dict | None = None, quiet: bool = False) -> list[Path]:
-    """Batched `initial_ocr` for this rank's share of `images`, then (with agents) the rest of the graph per page."""
+    """The batch folder: every rank reads its share of `images` in one batched engine pass; rank 0 gathers the token
+    streams and does the rest for all pages — detokenise, `initial_ocr` replay, (with agents) the critic / editor / re-OCR
+    loop, the four output files per page.  Returns the transcription paths on rank 0, [] elsewhere."""
     rank, _, world = shard.init_from_env()
-    mine = shard.shard([Path(p) for p in images], rank, world)
+    images = [Path(p) for p in images]
+    mine = shard.shard(images, rank, world)
     sink = io.StringIO() if quiet else None
-    reads: list = []
     with contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext():
-        states = initial_ocr_batched([str(p) for p in mine], params, speculate_reocr=bool(agents), reads_out=reads)
+        strategies, streams = read_pages([str(p) for p in mine], params, speculate_reocr=bool(agents))
+    streams = gather_reads(streams, len(images), len(strategies))
+    if streams is None:  # not rank 0: its reads are on their way to rank 0
+        return []
+    flat = tools.decode_tokens([t for page in streams for t in page])
+    k = len(strategies)
+    texts = [flat[p * k: (p + 1) * k] for p in range(len(images))]
+    with contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext():
+        states = replay_initial_ocr([str(p) for p in images], strategies, texts)
     outs = []
-    for state, (strategies, page_texts) in zip(states, reads):
+    for state, page_texts in zip(states, texts):
         if agents:
             nodes.run_critic, nodes.run_editor = agents["critic"], agents["editor"]
             nodes.run_arbitrator = agents.get("arbitrator")
@@ -215,10 +287,13 @@ def main(argv=None) -> None:
         print(f"No image files found in {src}", file=sys.stderr)
         sys.exit(1)
     out_dir = args.output_dir.resolve() if args.output_dir else (src / "results" if src.is_dir() else src.parent)
-    print(f"Found {len(images)} images in {src}")
+    rank = int(os.environ.get("RANK", "0"))
+    if rank == 0:
+        print(f"Found {len(images)} images in {src}")
     params = {"max_new_tokens": args.max_new_tokens} if args.max_new_tokens else None
     transcribe_folder(images, out_dir, args.ground_truth_dir, params)
-    print(f"\nAll done. Results saved to {out_dir}")
+    if rank == 0:
+        print(f"\nAll done. Results saved to {out_dir}")
 
 
 if __name__ == "__main__":

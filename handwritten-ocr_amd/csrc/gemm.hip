@@ -324,22 +324,27 @@ int launch_skinny(const SkinnyArgs& a, int epi, int splitk, bool tiled, hipStrea
 // ---- optional in-stream timing of gemm_wide launches (bench.py roofline leg): HIP events recorded on the launch
 // stream around every launch while enabled; a few microseconds of overhead per launch, no host sync.
 namespace {
-constexpr int PROF_CAP = 1 << 15;
 struct WideProfile {
   int on = 0;  // 1: time the bf16 wide launches, 2: the fp8 ones
-  int n = 0;
-  std::vector<hipEvent_t> ev;      // 2 per launch
+  int n = 0;   // launches recorded since the last enable
+  std::vector<hipEvent_t> ev;      // 2 per launch, created on demand and reused: no cap, no silently dropped launch
   std::vector<double> flops;
+  // events of launch n (created if this is the first time n launches are recorded); false if HIP refuses
+  bool slot(hipEvent_t& a, hipEvent_t& b) {
+    while ((int)ev.size() < 2 * (n + 1)) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return false;
+      ev.push_back(e);
+    }
+    if ((int)flops.size() < n + 1) flops.resize(n + 1);
+    a = ev[2 * n];
+    b = ev[2 * n + 1];
+    return true;
+  }
 } g_prof;
 }  // namespace
 
 extern "C" int hwocr_profile_enable(int on) {
-  if (on && g_prof.ev.empty()) {
-    g_prof.ev.resize(2 * PROF_CAP);
-    g_prof.flops.resize(PROF_CAP);
-    for (auto& e : g_prof.ev)
-      if (hipEventCreate(&e) != hipSuccess) return HWOCR_ELAUNCH;
-  }
   g_prof.on = on;
   if (on) g_prof.n = 0;
   return HWOCR_OK;
@@ -370,15 +375,16 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
   if (epi == EPI_RESIDUAL && (!res || (ldres % 4))) return HWOCR_EINVAL;
   WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)out,
              M, N, K, ldx, ldw, ldo, ldres, (M + BM - 1) / BM, (N + BN - 1) / BN};
-  const bool prof = g_prof.on == 1 && g_prof.n < PROF_CAP;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const bool prof = g_prof.on == 1 && g_prof.slot(ev0, ev1);
   static const bool use256 = [] { const char* e = getenv("HWOCR_GEMM256"); return !e || atoi(e) != 0; }();
   if (use256 && M >= 1024 && N >= 256 && (ldo % 8) == 0 && (epi != EPI_RESIDUAL || (ldres % 8) == 0)) {
-    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
+    if (prof) (void)hipEventRecord(ev0, stream);
     // HWOCR_GEMM_W4: 1 = the four-wave structure (gemm256x4.hip), 0 = the eight-wave one
     static const bool w4 = [] { const char* e = getenv("HWOCR_GEMM_W4"); return e && atoi(e) != 0; }();
     const int rc = w4 ? hwocr_gemm_wide256x4(a, epi, stream) : hwocr_gemm_wide256(a, epi, stream);
     if (prof) {
-      (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], stream);
+      (void)hipEventRecord(ev1, stream);
       g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
       ++g_prof.n;
     }
@@ -396,7 +402,7 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
     attr_done = true;
   }
-  if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
+  if (prof) (void)hipEventRecord(ev0, stream);
   switch (epi) {
     case EPI_LINEAR: hipLaunchKernelGGL(gemm_wide_kernel<EPI_LINEAR>, grid, block, WIDE_LDS, stream, a); break;
     case EPI_RESIDUAL: hipLaunchKernelGGL(gemm_wide_kernel<EPI_RESIDUAL>, grid, block, WIDE_LDS, stream, a); break;
@@ -408,7 +414,7 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
     default: return HWOCR_EINVAL;
   }
   if (prof) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], stream);
+    (void)hipEventRecord(ev1, stream);
     g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
     ++g_prof.n;
   }
@@ -426,11 +432,12 @@ extern "C" int hwocr_gemm_wide_fp8(const void* X8, const float* xscale, const vo
   if (epi == EPI_RESIDUAL && (!res || (ldres % 8))) return HWOCR_EINVAL;
   WideArgs a{(const bf16*)X8, (const bf16*)W8, (const bf16*)bias, (const bf16*)res, (bf16*)out,
              M, N, K, ldx, ldw, ldo, ldres, 0, 0, xscale, wscale};
-  const bool prof = g_prof.on == 2 && g_prof.n < PROF_CAP;
-  if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const bool prof = g_prof.on == 2 && g_prof.slot(ev0, ev1);
+  if (prof) (void)hipEventRecord(ev0, stream);
   const int rc = hwocr_gemm_wide256_fp8(a, epi, stream);
   if (prof) {
-    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], stream);
+    (void)hipEventRecord(ev1, stream);
     g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
     ++g_prof.n;
   }

@@ -71,6 +71,7 @@ class ModelConfig:
     # generation defaults of the checkpoint (generation_config.json): only the deterministic part is implemented — the
     # repetition penalty; temperatures of the Qwen-VL checkpoints (1e-6 .. 0.01 with top_k 1) make sampling the argmax
     repetition_penalty: float = 1.0
+    sampling_note: str = ""  # what generation_config.json asked for beyond greedy (see _apply_generation_config)
     # processor bounds (ocr_agent/config.py:17-18)
     min_pixels: int = 256 * 256
     max_pixels: int = 1024 * 1024
@@ -255,6 +256,37 @@ def normalize_keys(sd: dict) -> dict:
     return out
 
 
+def _apply_generation_config(cfg: ModelConfig, path: str) -> None:
+    """generation_config.json of the checkpoint = the defaults `model.generate(**inputs, max_new_tokens=...)` runs with in the
+    reference (tools.py:765 passes nothing else).  Honoured: eos_token_id (int or list), pad_token_id, repetition_penalty.
+    NOT built: multinomial sampling — HF draws with torch.multinomial from torch's RNG stream (generation/utils.py:2919-2925),
+    which no other implementation reproduces token for token; this engine always takes the argmax (HF do_sample=False).  That is
+    exact for top_k == 1 and indistinguishable for the near-zero temperatures the Qwen-VL / olmOCR checkpoints ship; for anything
+    else the divergence is recorded in cfg.sampling_note and printed once at load time."""
+    gen_path = os.path.join(path, "generation_config.json")
+    if not os.path.exists(gen_path):
+        return
+    with open(gen_path) as f:
+        g = json.load(f)
+    cfg.repetition_penalty = float(g.get("repetition_penalty") or 1.0)
+    eos = g.get("eos_token_id")
+    if eos is not None:
+        eos = tuple(int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos]))
+        if len(eos) > 4:
+            raise ValueError("generation_config.json lists more than 4 eos_token_id values (hwocr_gen_state.eos holds 4)")
+        cfg.eos_ids = eos
+    if g.get("pad_token_id") is not None:
+        cfg.pad_id = int(g["pad_token_id"])
+    if g.get("do_sample"):
+        t, k, p = g.get("temperature", 1.0), g.get("top_k", 50), g.get("top_p", 1.0)
+        if k == 1 or (t is not None and t <= 0.05):
+            cfg.sampling_note = f"do_sample with temperature {t}, top_k {k}: selects the argmax (greedy here is the same choice)"
+        else:
+            cfg.sampling_note = (f"checkpoint asks for sampling (temperature {t}, top_k {k}, top_p {p}); multinomial sampling is not "
+                                 "built: reads are greedy (HF do_sample=False), i.e. NOT what the reference would draw")
+            print(f"  [ocr] warning: {cfg.sampling_note}")
+
+
 def load_checkpoint_dir(path: str, device="cuda") -> tuple[ModelConfig, dict]:
     """Load config.json + *.safetensors of a Qwen2-VL / Qwen2.5-VL (olmOCR-2) checkpoint directory (safetensors only;
     nothing is unpickled)."""
@@ -278,6 +310,7 @@ def load_checkpoint_dir(path: str, device="cuda") -> tuple[ModelConfig, dict]:
             eps=tc.get("rms_norm_eps", 1e-6), tie=True,
             image_token_id=hf.get("image_token_index", hf.get("image_token_id", 257152)),  # PaliGemma serialises `_index`
             eos_ids=(hf.get("eos_token_id", 1),), pad_id=hf.get("pad_token_id", 0), bos_id=hf.get("bos_token_id", 2))
+        _apply_generation_config(cfg, path)
         sd = {}
         for fn in sorted(os.listdir(path)):
             if fn.endswith(".safetensors"):
@@ -297,10 +330,7 @@ def load_checkpoint_dir(path: str, device="cuda") -> tuple[ModelConfig, dict]:
         tie=bool(hf.get("tie_word_embeddings", tc.get("tie_word_embeddings", False))),
         image_token_id=hf.get("image_token_id", 151655), vision_start_id=hf.get("vision_start_token_id", 151652),
         vision_end_id=hf.get("vision_end_token_id", 151653))
-    gen_path = os.path.join(path, "generation_config.json")
-    if os.path.exists(gen_path):
-        with open(gen_path) as f:
-            cfg.repetition_penalty = float(json.load(f).get("repetition_penalty") or 1.0)
+    _apply_generation_config(cfg, path)
     sd = {}
     for fn in sorted(os.listdir(path)):
         if fn.endswith(".safetensors"):

@@ -141,10 +141,15 @@ class StrategyPages:
             img = getattr(self, name)(img)
         return img
 
-    def pages(self, page_rgb: np.ndarray, strategies: list, target_hw: tuple[int, int]) -> list[torch.Tensor]:
-        """One upload of the original page, every strategy's tower-resolution image resident in HBM.  Shared prefixes of
+    def pages(self, page_rgb, strategies: list, target_hw: tuple[int, int]) -> list[torch.Tensor]:
+        """page_rgb: RGB uint8 [H][W][3], a host array or a device tensor.  One upload of the original page, every strategy's tower-resolution image resident in HBM.  Shared prefixes of
         the chains (all of the reference's start with high_contrast) are computed once."""
-        base = torch.from_numpy(np.ascontiguousarray(page_rgb, dtype=np.uint8)).to(self.dev)
+        if isinstance(page_rgb, torch.Tensor):  # already resident in HBM (uint8 [H][W][3])
+            if page_rgb.dtype != torch.uint8 or page_rgb.dim() != 3 or page_rgb.shape[2] != 3:
+                raise ValueError("a device page must be uint8 [H][W][3]")
+            base = page_rgb.to(self.dev).contiguous()
+        else:
+            base = torch.from_numpy(np.array(page_rgb, dtype=np.uint8, order="C")).to(self.dev)  # (a copy: PIL arrays are read-only)
         cache: dict = {(): base}
         out = []
         for s in strategies:

@@ -132,6 +132,26 @@ def apply_strategy(img: Image.Image, strategy, quiet: bool = False) -> Image.Ima
     return img
 
 
+LOSSY_SUFFIXES = (".jpg", ".jpeg", ".webp")  # of the reference's IMAGE_EXTENSIONS (transcribe.py:29): saving re-quantises
+
+
+def through_tempfile_codec(img: Image.Image, suffix: str) -> Image.Image:
+    """What the next reader sees after `preprocess_image` saved `img` under the input's suffix (tools.py:668-672) and
+    `run_ocr` re-opened it (tools.py:745): for .jpg / .jpeg / .webp that is a lossy re-encode with Pillow's default
+    settings, for the other formats the same pixels.  In memory — the batched driver keeps no temp files."""
+    suffix = (suffix or ".png").lower()
+    if suffix not in LOSSY_SUFFIXES:
+        return img
+    import io
+
+    fmt = Image.registered_extensions()[suffix]
+    buf = io.BytesIO()
+    img.save(buf, format=fmt)
+    out = Image.open(io.BytesIO(buf.getvalue()))
+    out.load()
+    return out
+
+
 def preprocess_image(image_path: str, strategy) -> str:
     steps = steps_of(strategy)
     if not steps or steps == ["original"]:

@@ -41,21 +41,22 @@ def owner_index(n_items: int, world: int) -> list[tuple[int, int]]:
 
 def gather_token_streams(tokens: torch.Tensor, counts: torch.Tensor, dst: int = 0):
     """tokens int32 [reads_local, N], counts int32 [reads_local] -> on `dst`: list over ranks of (tokens, counts)
-    trimmed to each rank's own read count; elsewhere None.  Ranks may hold different numbers of reads: everything is
-    padded to the maximum so that a single fixed-shape gather moves it."""
+    trimmed to each rank's own read count and width; elsewhere None.  Ranks may hold different numbers of reads and
+    different widths N (reads stop at different lengths): everything is padded to the maxima so that ONE fixed-shape
+    gather moves it (<= 8 KB per read: latency-bound, any xGMI topology)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [(tokens, counts)]
     world, rank = dist.get_world_size(), dist.get_rank()
-    n_local = torch.tensor([tokens.shape[0]], dtype=torch.int32, device=tokens.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local)
-    n_max = int(max(int(s) for s in sizes))
-    width = tokens.shape[1]
-    buf = torch.zeros(n_max, width + 1, dtype=torch.int32, device=tokens.device)
-    buf[: tokens.shape[0], :width] = tokens
-    buf[: tokens.shape[0], width] = counts
+    shape = torch.tensor([tokens.shape[0], tokens.shape[1]], dtype=torch.int32, device=tokens.device)
+    shapes = [torch.zeros_like(shape) for _ in range(world)]
+    dist.all_gather(shapes, shape)
+    shapes = [s.cpu().tolist() for s in shapes]
+    n_max, w_max = max(s[0] for s in shapes), max(s[1] for s in shapes)
+    buf = torch.zeros(n_max, w_max + 1, dtype=torch.int32, device=tokens.device)
+    buf[: tokens.shape[0], : tokens.shape[1]] = tokens
+    buf[: tokens.shape[0], w_max] = counts
     out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, out, dst=dst)
     if rank != dst:
         return None
-    return [(out[r][: int(sizes[r]), :width], out[r][: int(sizes[r]), width]) for r in range(world)]
+    return [(out[r][: shapes[r][0], : shapes[r][1]], out[r][: shapes[r][0], w_max]) for r in range(world)]

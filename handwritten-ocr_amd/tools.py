@@ -11,10 +11,11 @@ HIP library or a GPU `run_ocr` raises), and `unload_ocr_model()` keeps the weigh
 HWOCR_KEEP_RESIDENT=0 — the reference drops them after every node so Ollama fits on a 48 GB laptop, which on a
 288 GB MI355X only buys a checkpoint reload per re-read.  `run_ocr_batch` is the batched entry the reference lacks.
 
-Model selection: HWOCR_MODEL = a checkpoint directory (config.json + *.safetensors [+ tokenizer.json]) or a preset
-name ("qwen2-vl-2b", "qwen2.5-vl-7b" = "olmocr-2-7b", "qwen2.5-vl-3b", "paligemma-3b", "small", "tiny", "tiny25",
-"tinypg"); presets are
-random-init because no checkpoint is reachable offline.
+Model selection: HWOCR_MODEL = a checkpoint directory (config.json + *.safetensors + tokenizer.json) — what the
+reference's `config.OLMOCR_MODEL` names, downloaded beforehand; it must be set.  The preset names ("qwen2-vl-2b",
+"qwen2.5-vl-7b" = "olmocr-2-7b", "qwen2.5-vl-3b", "paligemma-3b", "small", "tiny", "tiny25", "tinypg") build RANDOM-INIT
+weights with a byte tokenizer — plausible-looking noise, for benchmarks and tests only — and are refused unless
+HWOCR_ALLOW_RANDOM_INIT=1 says that is intended.
 """
 from __future__ import annotations
 
@@ -34,6 +35,14 @@ _ocr_model = None
 _ocr_processor = None
 
 
+def _device() -> str:
+    """One process per GPU: the rank's own device (LOCAL_RANK, set by torchrun / bench.py), else the current one."""
+    import torch
+
+    local = os.environ.get("LOCAL_RANK")
+    return f"cuda:{int(local)}" if local is not None else f"cuda:{torch.cuda.current_device()}"
+
+
 def _load_ocr_model():
     global _ocr_model, _ocr_processor
     if _ocr_model is not None:
@@ -44,22 +53,31 @@ def _load_ocr_model():
 
     if not torch.cuda.is_available():
         raise _lib.HwocrError("run_ocr needs an MI355X: the read engine has no CPU path")
-    spec = os.environ.get("HWOCR_MODEL", "qwen2-vl-2b")
-    print(f"  [ocr] Loading {spec} on cuda...")
+    spec = os.environ.get("HWOCR_MODEL")
+    if not spec:
+        raise _lib.HwocrError("HWOCR_MODEL is not set: point it at the checkpoint directory of the OCR model "
+                              f"(config.json + *.safetensors + tokenizer.json; the reference's default is {config.OLMOCR_MODEL!r})")
+    dev = _device()
+    # the reference prints its device class ("cuda" on ROCm torch, tools.py:692-699); ranks of a multi-GPU job add their index
+    print(f"  [ocr] Loading {spec} on {dev if os.environ.get('LOCAL_RANK') is not None else 'cuda'}...")
     if os.path.isdir(spec):
-        cfg, sd = engine.load_checkpoint_dir(spec)
-        tok = (tokenizer.HFTokenizer(cfg, spec) if os.path.exists(os.path.join(spec, "tokenizer.json"))
-               else tokenizer.ByteTokenizer(cfg))
+        if not os.path.exists(os.path.join(spec, "tokenizer.json")):
+            raise _lib.HwocrError(f"{spec} has no tokenizer.json: real weights with a stand-in tokenizer would decode to wrong text")
+        cfg, sd = engine.load_checkpoint_dir(spec, device=dev)
+        tok = tokenizer.HFTokenizer(cfg, spec)
     else:
+        if os.environ.get("HWOCR_ALLOW_RANDOM_INIT", "0") in ("", "0"):
+            raise _lib.HwocrError(f"HWOCR_MODEL={spec!r} is not a checkpoint directory.  Preset names build random-init weights "
+                                  "(noise, for benchmarks and tests): set HWOCR_ALLOW_RANDOM_INIT=1 if that is what you want")
         cfg = engine.preset(spec)
-        print("  [ocr] (no checkpoint directory given: random-init weights, byte-level tokenizer)")
-        sd = engine.random_state_dict(cfg, seed=int(os.environ.get("HWOCR_SEED", "0")))
+        print("  [ocr] (HWOCR_ALLOW_RANDOM_INIT: random-init weights, byte-level tokenizer — the text is noise)")
+        sd = engine.random_state_dict(cfg, seed=int(os.environ.get("HWOCR_SEED", "0")), device=dev)
         tok = tokenizer.ByteTokenizer(cfg, fold_unknown=True)
     cfg.min_pixels, cfg.max_pixels = config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS
     _ocr_model = engine.ReadEngine(cfg, sd, max_reads=int(os.environ.get("HWOCR_MAX_READS", "252")),
-                                   ctx=int(os.environ.get("HWOCR_CTX", "4096")),
+                                   ctx=int(os.environ.get("HWOCR_CTX", "4096")), device=dev,
                                    fp8=os.environ.get("HWOCR_FP8", "0") not in ("", "0"))
-    _ocr_processor = tokenizer.Processor(cfg, tok)
+    _ocr_processor = tokenizer.Processor(cfg, tok, template_dir=spec if os.path.isdir(spec) else None)
     print("  [ocr] Model loaded.")
     return _ocr_model, _ocr_processor
 
@@ -77,8 +95,9 @@ def unload_ocr_model():
     print("  [ocr] Model unloaded, memory freed.")
 
 
-def run_ocr_batch(images: list, params: dict | None = None) -> list[str]:
-    """Read many (already preprocessed) pages in one engine batch.  `images`: paths, PIL images, or uint8 [H][W][3] device
+def run_ocr_batch_tokens(images: list, params: dict | None = None) -> list[list[int]]:
+    """Read many (already preprocessed) pages in one engine batch; the generated token ids of every read (what the
+    multi-GPU driver gathers to rank 0, shard.gather_token_streams).  `images`: paths, PIL images, or uint8 [H][W][3] device
     tensors already at the tower's resolution (gpupre.StrategyPages)."""
     params = params or {}
     model, processor = _load_ocr_model()
@@ -96,10 +115,18 @@ def run_ocr_batch(images: list, params: dict | None = None) -> list[str]:
         pages.append(page)
         prompts.append(ids)
     # continuous batching: reads stop at different lengths (EOS), freed decode slots take the next read
-    streams = model.generate_stream(pages, prompts, max_new=max_new, min_new=min_new,
-                                    repetition_penalty=params.get("repetition_penalty"))  # None: the checkpoint's default
-    texts = [processor.decode(toks, skip_special_tokens=True) for toks in streams]
-    return texts
+    return model.generate_stream(pages, prompts, max_new=max_new, min_new=min_new,
+                                 repetition_penalty=params.get("repetition_penalty"))  # None: the checkpoint's default
+
+
+def decode_tokens(streams: list) -> list[str]:
+    """Generated ids -> text as the reference does it (tools.py:767-769: new tokens only, skip_special_tokens=True)."""
+    _, processor = _load_ocr_model()
+    return [processor.decode(toks, skip_special_tokens=True) for toks in streams]
+
+
+def run_ocr_batch(images: list, params: dict | None = None) -> list[str]:
+    return decode_tokens(run_ocr_batch_tokens(images, params))
 
 
 def run_ocr(image_path: str, params: dict | None = None) -> str:

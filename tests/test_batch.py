@@ -1,5 +1,6 @@
 """Batch-folder driver: one batched engine pass for all pages, then the reference's per-page node logic and output files.
-The engine is replaced by a scripted `run_ocr_batch` (CPU test); the node logic itself is pinned by tests/test_nodes.py."""
+The engine is replaced by a scripted `run_ocr_batch_tokens` (CPU test: tokens = the UTF-8 bytes of a scripted text); the node
+logic itself is pinned by tests/test_nodes.py."""
 import contextlib
 import io
 import json
@@ -12,6 +13,12 @@ from handwritten_ocr_amd import batch, tools
 from handwritten_ocr_amd.compat import config, nodes
 from handwritten_ocr_amd.compat.state import new_state
 from handwritten_ocr_amd.synth import make_page
+
+
+def _script_engine(monkeypatch, fn):
+    """fn(images, params) -> list of texts; installed at the token seam the batch driver uses."""
+    monkeypatch.setattr(tools, "run_ocr_batch_tokens", lambda images, params=None: [list(t.encode("utf-8")) for t in fn(images, params)])
+    monkeypatch.setattr(tools, "decode_tokens", lambda streams: [bytes(t).decode("utf-8") for t in streams])
 
 
 def _pages(tmp_path, n):
@@ -36,7 +43,7 @@ def test_batched_initial_ocr_equals_serial_node(tmp_path, monkeypatch):
         assert all(isinstance(im, Image.Image) for im in images)
         return [script[i // 3][i % 3] for i in range(len(images))]
 
-    monkeypatch.setattr(tools, "run_ocr_batch", fake_batch)
+    _script_engine(monkeypatch, fake_batch)
     with contextlib.redirect_stdout(io.StringIO()):
         states = batch.initial_ocr_batched([str(p) for p in paths])
     assert calls == [9]  # ONE engine pass for 3 pages x 3 strategies
@@ -62,7 +69,7 @@ def test_folder_outputs(tmp_path, monkeypatch):
     gtd = tmp_path / "gt"
     gtd.mkdir()
     (gtd / "page00.md").write_text("# doc\n\n## Ground Truth\n\nhello world\n")
-    monkeypatch.setattr(tools, "run_ocr_batch", lambda images, params=None: ["hello world"] * len(images))
+    _script_engine(monkeypatch, lambda images, params=None: ["hello world"] * len(images))
     assert [p.name for p in batch.list_images(tmp_path)] == ["page00.png", "page01.png"]
     out_dir = tmp_path / "results"
     outs = batch.transcribe_folder(batch.list_images(tmp_path), out_dir, gtd, quiet=True)
@@ -110,7 +117,7 @@ def test_reocr_rounds_are_answered_from_the_batched_pass(tmp_path, monkeypatch):
         return {"overall_confidence": 40, "verdict": "needs_reocr", "issues": []}
 
     agents = {"critic": critic, "editor": lambda t, c: {"corrected_text": t, "changes": []}, "arbitrator": Arb}
-    monkeypatch.setattr(tools, "run_ocr_batch", fake_batch)
+    _script_engine(monkeypatch, fake_batch)
     monkeypatch.setattr(nodes, "run_ocr", lambda *a, **k: pytest.fail("re-OCR must not enter the engine again"))
     monkeypatch.setattr(nodes, "unload_ocr_model", lambda: None)
     outs = batch.transcribe_folder(batch.list_images(tmp_path), tmp_path / "out", agents=agents, quiet=True)
@@ -123,3 +130,36 @@ def test_reocr_rounds_are_answered_from_the_batched_pass(tmp_path, monkeypatch):
         assert used == labels[: len(used)] and len(used) >= 3
         assert text == f"page {i} read with {used[-1]} words more words".upper()
         assert [e["action"] for e in ev][-3:] == ["arbitrate", "critique", "accept"]
+
+
+def test_lossy_input_formats_see_the_reference_reencode(tmp_path, monkeypatch):
+    """the serial path hands every transformed page to the model through a temp file with the INPUT's suffix
+    (tools.py:668-672), which for .jpg re-quantises the pixels.  The batched driver must feed the engine the same pixels:
+    compare what it hands over with what `preprocess_image` + `Image.open` (the serial path) produce, page by page."""
+    from handwritten_ocr_amd import preprocess
+
+    src = tmp_path / "photo.jpg"
+    Image.fromarray(make_page(3, 120, 160), "RGB").save(src, quality=92)
+    png = tmp_path / "scan.png"
+    Image.fromarray(make_page(4, 120, 160), "RGB").save(png)
+    seen = []
+
+    def fake(images, params=None):
+        seen.extend(images)
+        return ["t"] * len(images)
+
+    _script_engine(monkeypatch, fake)
+    with contextlib.redirect_stdout(io.StringIO()):
+        strategies, _ = batch.read_pages([str(src), str(png)])
+    k = len(strategies)
+    assert len(seen) == 2 * k
+    for p, path in enumerate((src, png)):
+        for j, s in enumerate(strategies):
+            with contextlib.redirect_stdout(io.StringIO()):
+                serial = Image.open(preprocess.preprocess_image(str(path), s))
+            got = seen[p * k + j]
+            assert got.mode == serial.mode and got.size == serial.size
+            assert np.array_equal(np.asarray(got), np.asarray(serial)), (path.name, s)
+    # and the re-encode is not a no-op for the JPEG page (the round-1 driver skipped it)
+    direct = preprocess.apply_strategy(Image.open(src), strategies[0], quiet=True)
+    assert not np.array_equal(np.asarray(direct.convert("RGB")), np.asarray(seen[0].convert("RGB")))

@@ -62,3 +62,24 @@ def test_key_normalisation_of_older_layouts():
                    "model.language_model.norm.weight": 3, "lm_head.weight": 4, "model.visual.merger.ln_q.weight": 5,
                    "model.vision_tower.encoder.layers.0.layer_norm1.weight": 6, "model.multi_modal_projector.linear.bias": 7,
                    "model.language_model.layers.1.self_attn.q_proj.weight": 8, "model.vision_tower.post_layernorm.bias": 9}
+
+
+@pytest.mark.parametrize("gen,eos,pad,rp,note", [
+    ({"do_sample": True, "temperature": 0.01, "top_k": 1, "top_p": 0.001, "repetition_penalty": 1.05,
+      "eos_token_id": [505, 510], "pad_token_id": 511}, (505, 510), 511, 1.05, "argmax"),          # the Qwen2-VL model-card shape
+    ({"do_sample": True, "temperature": 0.8, "top_k": 50, "eos_token_id": 505}, (505,), 511, 1.0, "NOT what the reference would draw"),
+    ({"eos_token_id": 510}, (510,), 511, 1.0, ""),
+])
+def test_generation_config_defaults(tmp_path, capsys, gen, eos, pad, rp, note):
+    """generation_config.json written by HF's own GenerationConfig.save_pretrained: EOS set, pad id and repetition penalty
+    are taken over; sampling settings that amount to the argmax pass silently, real sampling is declared unbuilt."""
+    import transformers as tf
+
+    _write_dir(tmp_path, "qwen2_vl")
+    tf.GenerationConfig(**gen).save_pretrained(tmp_path)
+    cfg, _ = engine.load_checkpoint_dir(str(tmp_path), device="cpu")
+    assert (tuple(cfg.eos_ids), cfg.repetition_penalty) == (eos, rp)
+    assert cfg.pad_id == (gen.get("pad_token_id", engine.ModelConfig().pad_id))
+    assert note in cfg.sampling_note
+    printed = capsys.readouterr().out
+    assert ("warning" in printed) == ("NOT" in note)

@@ -74,6 +74,7 @@ def test_batched_driver_with_device_preprocessing_gives_the_same_states(tmp_path
     if preprocess._cv2() is not None:
         pytest.skip("OpenCV present")
     monkeypatch.setenv("HWOCR_MODEL", "tiny")
+    monkeypatch.setenv("HWOCR_ALLOW_RANDOM_INIT", "1")
     monkeypatch.setenv("HWOCR_MAX_READS", "8")
     monkeypatch.setenv("HWOCR_CTX", "512")
     monkeypatch.setattr(tools, "_ocr_model", None)

@@ -244,6 +244,7 @@ def test_drop_in_tools_surface(tmp_path, monkeypatch, capsys):
     from handwritten_ocr_amd.synth import make_page
 
     monkeypatch.setenv("HWOCR_MODEL", "tiny")
+    monkeypatch.setenv("HWOCR_ALLOW_RANDOM_INIT", "1")
     monkeypatch.setenv("HWOCR_MAX_READS", "8")
     monkeypatch.setenv("HWOCR_CTX", "512")
     monkeypatch.setattr(tools, "_ocr_model", None)
@@ -287,6 +288,7 @@ def test_batch_folder_cli_end_to_end(tmp_path, monkeypatch, capsys):
     from handwritten_ocr_amd.synth import make_page
 
     monkeypatch.setenv("HWOCR_MODEL", "tiny")
+    monkeypatch.setenv("HWOCR_ALLOW_RANDOM_INIT", "1")
     monkeypatch.setenv("HWOCR_MAX_READS", "4")   # fewer slots than reads: the continuous-batching path refills them
     monkeypatch.setenv("HWOCR_CTX", "512")
     monkeypatch.setattr(tools, "_ocr_model", None)
@@ -295,8 +297,9 @@ def test_batch_folder_cli_end_to_end(tmp_path, monkeypatch, capsys):
     monkeypatch.setattr(config, "OCR_MAX_NEW_TOKENS", 24)
     folder = tmp_path / "pages"
     folder.mkdir()
-    for i in range(3):
-        Image.fromarray(make_page(60 + i, 70, 100), "RGB").save(folder / f"p{i}.png")
+    names = ["p0.png", "p1.jpg", "p2.png"]  # the .jpg page: the serial path re-encodes every transformed read (tools.py:668-672)
+    for i, n in enumerate(names):
+        Image.fromarray(make_page(60 + i, 70, 100), "RGB").save(folder / n)
     batch.main([str(folder), "--output-dir", str(tmp_path / "out")])
     capsys.readouterr()
     for i in range(3):
@@ -307,9 +310,73 @@ def test_batch_folder_cli_end_to_end(tmp_path, monkeypatch, capsys):
         # the serial path on the same engine: per-read run_ocr through the same node
         from handwritten_ocr_amd.compat import nodes
         from handwritten_ocr_amd.compat.state import new_state
-        state = new_state(str(folder / f"p{i}.png"), config)
+        state = new_state(str(folder / names[i]), config)
         state.update(nodes.node_initial_ocr(state))
         capsys.readouterr()
         assert state["current_best"] == txt
+
+
+def test_agent_loop_on_the_real_engine(tmp_path, monkeypatch, capsys):
+    """BASELINE config 5 / SURVEY 8f-4 on the MI355X: `transcribe_folder(agents=...)` with scripted critic / editor /
+    arbitrator (the LLM agents are out of scope) on the tiny preset.  The critic forces one `reocr`; the engine must be
+    entered ONCE (every distinct strategy read in the batched pass, the re-read answered from it) and every page must end
+    exactly where the serial graph (`run_graph`: per-read `run_ocr`, one engine call each, nodes.py:239-302) ends."""
+    import json
+
+    from handwritten_ocr_amd import batch, tools
+    from handwritten_ocr_amd.compat import config, nodes
+    from handwritten_ocr_amd.compat.state import new_state
+    from handwritten_ocr_amd.synth import make_page
+
+    monkeypatch.setenv("HWOCR_MODEL", "tiny")
+    monkeypatch.setenv("HWOCR_ALLOW_RANDOM_INIT", "1")
+    monkeypatch.setenv("HWOCR_MAX_READS", "6")
+    monkeypatch.setenv("HWOCR_CTX", "512")
+    monkeypatch.setattr(tools, "_ocr_model", None)
+    monkeypatch.setattr(tools, "_ocr_processor", None)
+    monkeypatch.setattr(config, "OCR_MIN_PIXELS", 28 * 28)
+    monkeypatch.setattr(config, "OCR_MAX_NEW_TOKENS", 20)
+    folder = tmp_path / "pages"
+    folder.mkdir()
+    for i in range(2):
+        Image.fromarray(make_page(80 + i, 70, 100), "RGB").save(folder / f"q{i}.png")
+
+    class Arb:
+        def __init__(self, versions):
+            self.final_text, self.confidence = versions[-1]["text"] + " [arbitrated]", 70
+            self.decisions, self.uncertain_segments = [], []
+
+        def model_dump(self):
+            return {"final_text": self.final_text, "confidence": self.confidence}
+
+    def critic(text, previous_critique=None):
+        if text.endswith("[arbitrated]"):
+            return {"overall_confidence": 95, "verdict": "accept", "issues": []}
+        return {"overall_confidence": 40, "verdict": "needs_reocr", "issues": []}
+
+    agents = {"critic": critic, "editor": lambda t, c: {"corrected_text": t, "changes": []}, "arbitrator": Arb}
+    entered = []
+
+    def counting_tokens(images, params=None):
+        entered.append(len(images))
+        return real_tokens(images, params)
+
+    real_tokens = tools.run_ocr_batch_tokens
+    monkeypatch.setattr(tools, "run_ocr_batch_tokens", counting_tokens)
+    outs = batch.transcribe_folder(batch.list_images(folder), tmp_path / "out", agents=agents, quiet=True)
+    distinct = batch._speculative_strategies(list(config.PREPROCESSING_STRATEGIES), every=True)
+    assert entered == [2 * len(distinct)], "the agent loop must not re-enter the engine for a re-read"
+    # the serial graph on the same engine
+    monkeypatch.setattr(nodes, "run_critic", agents["critic"])
+    monkeypatch.setattr(nodes, "run_editor", agents["editor"])
+    monkeypatch.setattr(nodes, "run_arbitrator", agents["arbitrator"])
+    for i, o in enumerate(outs):
+        serial = nodes.run_graph(new_state(str(folder / f"q{i}.png"), config))
+        capsys.readouterr()
+        assert o.read_text() == serial["current_best"] and serial["current_best"].endswith("[arbitrated]")
+        ev = json.loads((tmp_path / "out" / f"q{i}_trace.json").read_text())
+        assert [e["action"] for e in ev] == [e["action"] for e in serial["trace_events"]]
+        assert "reocr" in [e.get("agent") for e in ev] or any(e["action"] == "arbitrate" for e in ev)
+        assert json.loads((tmp_path / "out" / f"q{i}_eval.json").read_text())["pipeline_status"] == serial["status"]
     monkeypatch.setenv("HWOCR_KEEP_RESIDENT", "0")
     tools.unload_ocr_model()

@@ -5,11 +5,14 @@ Sources of truth
   * string / preprocessing / node control-flow KATs: the reference's own Python, imported from /root/reference with an
     inert `ollama` module in sys.modules (ocr_agent/tools.py:146 imports it at module level; nothing on the paths
     exercised here calls it).  cv2 is absent in this image, so preprocessing KATs pin the PIL fallbacks.
+  * processor / chat-template / tokenizer KATs (tests/golden/tokenizer_tiny/ + tokenizer_kats.json): HF's
+    PreTrainedTokenizerFast over a tiny byte-level BPE trained here, with the Qwen2-VL chat template, and HF's PIL image
+    processor — the objects run_ocr's processor is made of (tools.py:744-769): rendered chat text, prompt ids, decode strings.
   * image-processor and model KATs: Hugging Face transformers (the library run_ocr drives, tools.py:690-765) on tiny
     seeded random-init Qwen2-VL models — no checkpoint is available offline.
 
 Only data is written: inputs, expected outputs, weights of the random tiny model.  No reference source text.
-Usage: python tools/make_goldens.py [--only text,preprocess,nodes,image,model]
+Usage: python tools/make_goldens.py [--only text,preprocess,nodes,image,model,model25,paligemma,tokenizer]
 """
 from __future__ import annotations
 
@@ -557,9 +560,99 @@ def make_model_paligemma() -> None:
         os.chmod(os.path.join(GOLD, fn), 0o644)
 
 
+# ------------------------------------------------------------------------------------------------ processor / tokenizer
+# the chat template the Qwen2-VL / Qwen2.5-VL / olmOCR-2 checkpoints ship (chat_template.json of the public model cards)
+QWEN2VL_CHAT_TEMPLATE = (
+    "{% set image_count = namespace(value=0) %}{% set video_count = namespace(value=0) %}{% for message in messages %}"
+    "{% if loop.first and message['role'] != 'system' %}<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n{% endif %}"
+    "<|im_start|>{{ message['role'] }}\n{% if message['content'] is string %}{{ message['content'] }}<|im_end|>\n{% else %}"
+    "{% for content in message['content'] %}{% if content['type'] == 'image' or 'image' in content or 'image_url' in content %}"
+    "{% set image_count.value = image_count.value + 1 %}{% if add_vision_id %}Picture {{ image_count.value }}: {% endif %}"
+    "<|vision_start|><|image_pad|><|vision_end|>{% elif content['type'] == 'video' or 'video' in content %}"
+    "{% set video_count.value = video_count.value + 1 %}{% if add_vision_id %}Video {{ video_count.value }}: {% endif %}"
+    "<|vision_start|><|video_pad|><|vision_end|>{% elif 'text' in content %}{{ content['text'] }}{% endif %}{% endfor %}<|im_end|>\n"
+    "{% endif %}{% endfor %}{% if add_generation_prompt %}<|im_start|>assistant\n{% endif %}")
+TOK_SPECIALS = ["<|endoftext|>", "<|im_start|>", "<|im_end|>", "<|vision_start|>", "<|vision_end|>", "<|vision_pad|>",
+                "<|image_pad|>", "<|video_pad|>"]
+
+
+def make_tokenizer() -> None:
+    """tests/golden/tokenizer_tiny/: a checkpoint-shaped directory (tokenizer.json, tokenizer_config.json, chat template,
+    preprocessor_config.json) saved by HF's own save_pretrained; tests/golden/tokenizer_kats.json: what
+    processor.apply_chat_template / processor.decode return for it — the calls of ocr_agent/tools.py:756-769."""
+    from PIL import Image
+    from tokenizers import AddedToken, Regex, Tokenizer, decoders, models, normalizers, pre_tokenizers, processors, trainers
+    from transformers import PreTrainedTokenizerFast
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+
+    # byte-level BPE built like Qwen2's tokenizer.json: NFC, the GPT-4-style split pattern, ByteLevel, no prefix space
+    tok = Tokenizer(models.BPE())
+    tok.normalizer = normalizers.NFC()
+    pat = (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+")
+    tok.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split(Regex(pat), behavior="isolated", invert=False),
+                                                 pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+    tok.decoder = decoders.ByteLevel()
+    tok.post_processor = processors.ByteLevel(trim_offsets=False)
+    rng = random.Random(11)
+    corpus = ["Extract and return all the text from this handwritten document.", "You are a helpful assistant.",
+              "system user assistant", "Dear Anna, thank you for the letter — it arrived on 3 May. “Quoted” text, naïve café."]
+    corpus += [_rand_text(rng, rng.randint(5, 30)) for _ in range(60)]
+    tok.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=480, special_tokens=[], show_progress=False,
+                                                        initial_alphabet=pre_tokenizers.ByteLevel.alphabet()))
+    tok.add_special_tokens([AddedToken(t, special=True, normalized=False) for t in TOK_SPECIALS])
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|im_end|>", pad_token="<|endoftext|>",
+                                   additional_special_tokens=TOK_SPECIALS[1:])
+
+    # Qwen2VLProcessor itself cannot be constructed here (it insists on a video processor, whose class needs torchvision —
+    # absent), so its three steps are driven one by one on HF's own objects: the chat-template renderer
+    # (tokenizer.apply_chat_template -> utils/chat_template_utils.render_jinja_template, the function the processor calls), the
+    # placeholder expansion `image_token * (grid.prod() // merge^2)` (processing_qwen2_vl.py:58-61, the one restated line) with
+    # the grid from HF's PIL image processor, and tokenizer.__call__.
+    fast.chat_template = QWEN2VL_CHAT_TEMPLATE
+    ip = Qwen2VLImageProcessorPil(min_pixels=28 * 28, max_pixels=1024 * 1024)
+    out_dir = os.path.join(GOLD, "tokenizer_tiny")
+    os.makedirs(out_dir, exist_ok=True)
+    for fn in os.listdir(out_dir):
+        os.remove(os.path.join(out_dir, fn))
+    fast.save_pretrained(out_dir)
+    ip.save_pretrained(out_dir)
+    ids = {t: tok.token_to_id(t) for t in TOK_SPECIALS}
+    cases = []
+    prompts = ["Extract and return all the text from this handwritten document.", "Read the page.\nKeep line breaks!",
+               "Qu’est-ce que c’est — naïve café? 日本語 42"]
+    for i, ((h, w), prompt) in enumerate(zip(((84, 112), (56, 56), (300, 140)), prompts)):
+        img = Image.fromarray(make_page(i, h, w), "RGB")
+        messages = [{"role": "user", "content": [{"type": "image", "url": f"p{i}.png"}, {"type": "text", "text": prompt}]}]
+        text = fast.apply_chat_template(messages, add_generation_prompt=True, tokenize=False)
+        grid = ip(images=[img], return_tensors="pt")["image_grid_thw"][0]
+        n_tok = int(grid.prod()) // ip.merge_size ** 2
+        assert text.count("<|image_pad|>") == 1
+        expanded = text.replace("<|image_pad|>", "<|image_pad|>" * n_tok)
+        cases.append({"page_hw": [h, w], "prompt": prompt, "rendered": text, "image_grid_thw": grid.tolist(),
+                      "input_ids": fast(expanded)["input_ids"]})
+    proc = fast  # processor.decode forwards to tokenizer.decode (processing_utils.py:1939-1946)
+    dec = []
+    texts = ["Dear Anna, thank you for the letter.", "line one\nline two\n\n  indented", "café — “quoted” 日本",
+             " leading space and trailing space ", "it 's a test , really !", ""]
+    for t in texts:
+        body = tok.encode(t, add_special_tokens=False).ids
+        for tail in ([], [ids["<|im_end|>"]], [ids["<|im_end|>"], ids["<|endoftext|>"], ids["<|endoftext|>"]]):
+            seq = body + tail
+            dec.append({"ids": seq, "skip": proc.decode(seq, skip_special_tokens=True), "keep": proc.decode(seq, skip_special_tokens=False)})
+    # truncated multi-byte characters (a generation cut by max_new_tokens) and specials inside the stream
+    cut = tok.encode("日本語", add_special_tokens=False).ids[:-1]
+    for seq in (cut, [ids["<|vision_start|>"]] + tok.encode("mid", add_special_tokens=False).ids + [ids["<|vision_end|>"]] + cut):
+        dec.append({"ids": seq, "skip": proc.decode(seq, skip_special_tokens=True), "keep": proc.decode(seq, skip_special_tokens=False)})
+    enc_kats = [{"text": t, "ids": fast(t)["input_ids"]} for t in texts + prompts + ["<|im_start|>user\n<|vision_start|><|image_pad|><|image_pad|><|vision_end|>x<|im_end|>\n"]]
+    with open(os.path.join(GOLD, "tokenizer_kats.json"), "w", encoding="utf-8") as f:
+        json.dump({"source": "transformers PreTrainedTokenizerFast(tiny byte-level BPE).apply_chat_template(Qwen2-VL template) / __call__ / "
+                             "decode + Qwen2VLImageProcessorPil grids; the <|image_pad|> expansion is Qwen2VLProcessor.replace_image_token restated",
+                   "special_ids": ids, "chat": cases, "decode": dec, "encode": enc_kats}, f, indent=0, ensure_ascii=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="text,preprocess,nodes,image,model,model25,paligemma")
+    ap.add_argument("--only", default="text,preprocess,nodes,image,model,model25,paligemma,tokenizer")
     only = set(ap.parse_args().only.split(","))
     os.makedirs(GOLD, exist_ok=True)
     if only & {"text", "preprocess"}:
@@ -578,6 +671,8 @@ def main() -> None:
         make_model("qwen2_5_vl")
     if "paligemma" in only:
         make_model_paligemma()
+    if "tokenizer" in only:
+        make_tokenizer()
 
 
 if __name__ == "__main__":
