@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of hwocr_gemm_wide at the page-read shapes (MI355X).  TFLOP/s from torch CUDA events."""
+"""Micro-benchmark of hwocr_gemm_wide at the page-read shapes (MI355X).  TFLOP/s from torch CUDA events.
+With `lib` as the first argument the same contraction through torch's library GEMM (hipBLASLt / rocBLAS, no epilogue) is
+timed beside it — a yardstick for what a tuned vendor kernel reaches on these shapes, never part of the product."""
 import os
 import sys
 
@@ -39,4 +41,16 @@ for name, M, N, K, epi in SHAPES:
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f"{name:12s} M={M:6d} N={N:6d} K={K:5d} epi={epi}  {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s", flush=True)
+    extra = ""
+    if len(sys.argv) > 1 and sys.argv[1] == "lib":
+        for _ in range(3):
+            torch.nn.functional.linear(x, w)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            torch.nn.functional.linear(x, w)
+        e1.record()
+        torch.cuda.synchronize()
+        ml = e0.elapsed_time(e1) / reps
+        extra = f"   | torch linear (library GEMM, no epilogue) {ml:8.3f} ms {2.0 * M * N * K / ml / 1e9:8.1f} TFLOP/s"
+    print(f"{name:12s} M={M:6d} N={N:6d} K={K:5d} epi={epi}  {ms:8.3f} ms  {2.0 * M * N * K / ms / 1e9:8.1f} TFLOP/s{extra}", flush=True)
