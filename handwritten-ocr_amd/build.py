@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-HIP_SOURCES = ["gemm.hip", "gemm256.hip", "gemm256x4.hip", "gemm_stream.hip", "attention.hip", "elementwise.hip", "imagepre.hip", "runtime.hip"]
+HIP_SOURCES = ["gemm.hip", "gemm256.hip", "gemm_stream.hip", "attention.hip", "elementwise.hip", "imagepre.hip", "runtime.hip"]
 HIP_LIB = os.path.join(CSRC, "libhwocr_hip.so")
 TEXT_LIB = os.path.join(CSRC, "libhwocr_text.so")
 

@@ -380,9 +380,7 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
   static const bool use256 = [] { const char* e = getenv("HWOCR_GEMM256"); return !e || atoi(e) != 0; }();
   if (use256 && M >= 1024 && N >= 256 && (ldo % 8) == 0 && (epi != EPI_RESIDUAL || (ldres % 8) == 0)) {
     if (prof) (void)hipEventRecord(ev0, stream);
-    // HWOCR_GEMM_W4: 1 = the four-wave structure (gemm256x4.hip), 0 = the eight-wave one
-    static const bool w4 = [] { const char* e = getenv("HWOCR_GEMM_W4"); return e && atoi(e) != 0; }();
-    const int rc = w4 ? hwocr_gemm_wide256x4(a, epi, stream) : hwocr_gemm_wide256(a, epi, stream);
+    const int rc = hwocr_gemm_wide256(a, epi, stream);
     if (prof) {
       (void)hipEventRecord(ev1, stream);
       g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;

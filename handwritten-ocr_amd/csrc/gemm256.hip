@@ -15,6 +15,14 @@
 //     phase earlier.  Only ph3 waits, with a COUNTED vmcnt that retires the next K tile and leaves 3 units in flight.
 // The weight tile is the MFMA A operand, so each lane owns 4 consecutive output features (8-byte stores).
 //
+// Persistent tile loop (round 2).  The grid is one workgroup per CU; workgroup b walks output tiles b, b + grid, ... .  With one
+// tile per workgroup (round 1) a CU spent, per 45 us tile of the K = 1280 tower GEMMs, ~1.5 us waiting for the next workgroup
+// to be dispatched and ~2 us for its first K tile to arrive, with the matrix pipe idle.  Now, as soon as the last K tile of a
+// tile has been multiplied, the 7 prologue units of the NEXT tile are issued, and only then does the epilogue of the finished
+// tile run (bias + activation in registers, staged through a 4-KiB-per-wave LDS region of its own — the operand stages belong to
+// the prologue DMAs by then — and stored as whole 128-byte rows): the first K tiles land under the epilogue, and the epilogue's
+// stores drain under the next tile's first K tiles (counted wait between two tiles, see the end of the loop).
+//
 // FP8 variant (BASELINE config 4: E4M3 weights + activations): the SAME byte-level pipeline over rows of 128 fp8 values
 // (a K tile = 128 elements, so half as many K tiles), multiplied with v_mfma_f32_16x16x128_f8f6f4 (the 2x-rate form): a
 // lane's 32-byte operand = the two 16-byte chunks the bf16 form feeds to its two k-steps.  The k order inside the
@@ -31,7 +39,8 @@ namespace {
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int TILE = 256 * BK * 2;   // 32 KiB per operand tile
 constexpr int STAGE = 2 * TILE;      // activation tile, then weight tile
-constexpr int LDS_BYTES = 2 * STAGE; // 128 KiB
+constexpr int EPI_STAGE = 8 * 4096;  // epilogue staging: 4 KiB per wave, apart from the operand stages (see the tile loop)
+constexpr int LDS_BYTES = 2 * STAGE + EPI_STAGE;  // 128 + 32 = 160 KiB: the whole LDS of a CU
 constexpr int AHEAD = 7;             // units in flight ahead of the consuming phase
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -82,6 +91,11 @@ __device__ __forceinline__ void wait_units_in_flight(int units) {  // 2 DMA inst
   }
 }
 
+// Timeline build (HWOCR_GEMM_ABLATE=10, tools/bench_gemm_timeline.py): wave 0 of every workgroup stamps the 100 MHz wall clock
+// at the start of each tile's main loop, at its end and after the epilogue; results stay correct.
+constexpr int TL_MAX = 256 * 64 * 4;
+__device__ unsigned long long g_timeline[TL_MAX];
+
 // STAGGER: the two wave-rows run half a phase apart (load segment | multiply segment, a barrier between segments): while
 // waves 0-3 multiply, waves 4-7 fetch their fragments and vice versa, so the matrix pipe of every SIMD always has one of
 // its two waves ready.  Costs a second barrier per phase; LDS hazards hold because every unit is overwritten 7 phases
@@ -95,9 +109,15 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
   const int wr = w >> 2, wc = w & 3;
-  int tm, tn;
-  tile_of_block(a.tilesM, a.tilesN, 4, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int ntiles = a.tilesM * a.tilesN;
+  int tile = blockIdx.x;
+  int m0, n0;
+  auto origin_of = [&](int id) {  // XCD-contiguous chunks, then 4 row panels swept column-major (gemm_common.cuh)
+    int tm, tn;
+    tile_of_id(id, a.tilesM, a.tilesN, 4, tm, tn);
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
 
   // ---- staging plan.  Unit kind k, instruction j: this thread copies one 16-byte chunk of tile row ubase[k] + r8 + 128 j
   // (8 consecutive rows = 1 KiB per wave-instruction, lane-linear in LDS).
@@ -107,15 +127,17 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
                         (w >> 2) * 64 + (w & 3) * 8 + 32,  // U2: weight rows {32..63, 96..127} (+128)
                         64 + 8 * w};                     // U3: activation rows 64..127 (+128)
   const char* usrc[4][2];
+  auto set_sources = [&]() {
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = ubase[k] + r8 + 128 * j;
-      const int lc = p ^ ((row >> 1) & 7);
-      usrc[k][j] = (k == 1 || k == 2) ? (const char*)a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw * ES + lc * 16
-                                      : (const char*)a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx * ES + lc * 16;
-    }
+      for (int j = 0; j < 2; ++j) {
+        const int row = ubase[k] + r8 + 128 * j;
+        const int lc = p ^ ((row >> 1) & 7);
+        usrc[k][j] = (k == 1 || k == 2) ? (const char*)a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw * ES + lc * 16
+                                        : (const char*)a.X + (size_t)min(m0 + row, a.M - 1) * a.ldx * ES + lc * 16;
+      }
+  };
   const int nk = a.K * ES / 128;
   auto issue = [&](auto kind, int t) {  // unit (t, kind): 2 LDS-DMA instructions per thread
     constexpr int k = decltype(kind)::value;
@@ -130,12 +152,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   using K2 = std::integral_constant<int, 2>;
   using K3 = std::integral_constant<int, 3>;
   const int total_units = 4 * nk;
-
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto issue_prologue = [&]() {  // 7 units: K tile 0 and three quarters of K tile 1
+    issue(K0{}, 0); issue(K1{}, 0); issue(K2{}, 0); issue(K3{}, 0);
+    issue(K0{}, 1); issue(K1{}, 1); issue(K2{}, 1);
+  };
 
   // fragment addresses inside a stage: row*128 + ((chunk ^ ((row>>1)&7)) << 4), rows = 16-aligned base + c
   const int sw = (c >> 1) & 7;
@@ -169,152 +189,255 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue: 7 units in flight, K tile 0 (units 0..3) landed
-  issue(K0{}, 0); issue(K1{}, 0); issue(K2{}, 0); issue(K3{}, 0);
-  issue(K0{}, 1); issue(K1{}, 1); issue(K2{}, 1);
+  // ---- first tile: 7 units in flight, K tile 0 (units 0..3) landed
+  origin_of(tile);
+  set_sources();
+  issue_prologue();
   wait_units_in_flight(max(0, min(3, total_units - 4)));
   phase_end();
 
-  if constexpr (!STAGGER) {
-    for (int t = 0; t < nk; ++t) {
-      const char* st = smem + (t & 1) * STAGE;
-      const int P = 4 * t;
-      // ph0: (m0, n0)
-      read_x(st, 0);
-      read_w(st, 0, wf[0]);
-      issue(K3{}, t + 1);  // unit P + 7
-      if constexpr (ABL != 2) quadrant_mma<FP8, 0, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
-      phase_end();
-      // ph1: (m0, n1)
-      read_w(st, 1, wf[1]);
-      issue(K0{}, t + 2);
-      if constexpr (ABL != 2) quadrant_mma<FP8, 0, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
-      phase_end();
-      // ph2: (m1, n1)
-      read_x(st, 1);
-      issue(K1{}, t + 2);
-      if constexpr (ABL != 2) quadrant_mma<FP8, 1, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
-      phase_end();
-      // ph3: (m1, n0); retire K tile t+1, keep the units issued behind it in flight
-      issue(K2{}, t + 2);
-      if constexpr (ABL != 2) quadrant_mma<FP8, 1, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
-      wait_units_in_flight(max(0, min(3, total_units - 1 - (P + 7))));
-      phase_end();
+  int tl_i = 0;
+  auto stamp = [&](int what) {
+    if constexpr (ABL == 10) {
+      if (tid == 0) {
+        const int slot = (blockIdx.x * 64 + tl_i) * 4 + what;
+        if (slot < TL_MAX) {
+          g_timeline[slot] = wall_clock64();
+          if (what == 0) g_timeline[slot + 3] = clock64();  // shader clock beside the wall clock: the clock rate under load
+        }
+      }
     }
-  } else {
-    const bool late = wr == 1;  // wave-uniform
-    if (late) phase_end();
-    for (int t = 0; t < nk; ++t) {
-      const char* st = smem + (t & 1) * STAGE;
-      const int keep = max(0, min(3, total_units - 1 - (4 * t + 7)));
-      read_x(st, 0);
-      read_w(st, 0, wf[0]);
-      issue(K3{}, t + 1);
-      phase_end();
-      if constexpr (ABL != 2) quadrant_mma<FP8, 0, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
-      phase_end();
-      read_w(st, 1, wf[1]);
-      issue(K0{}, t + 2);
-      phase_end();
-      if constexpr (ABL != 2) quadrant_mma<FP8, 0, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
-      phase_end();
-      read_x(st, 1);
-      issue(K1{}, t + 2);
-      phase_end();
-      if constexpr (ABL != 2) quadrant_mma<FP8, 1, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
-      phase_end();
-      issue(K2{}, t + 2);
-      if (late) wait_units_in_flight(keep);
-      phase_end();
-      if constexpr (ABL != 2) quadrant_mma<FP8, 1, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
-      if (!late) wait_units_in_flight(keep);
-      phase_end();
-    }
-    if (!late) phase_end();
-  }
+  };
+  while (true) {
+    stamp(0);
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- epilogue: lane (c,q) of tile (nt,mt) holds out[m0 + 128wr + 16mt + c][n0 + 64wc + 16nt + 4q .. +3]
-  if constexpr (ABL == 5) {  // no epilogue: the accumulators only have to stay alive
-    float sum = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) sum += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
-    if (sum == 12345.678f) a.out[0] = f2bf(sum);
-    return;
-  }
-  if constexpr (FP8) {
-    float xs[8];
-    f32x4 ws[4];
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) xs[mt] = a.xscale[min(m0 + 128 * wr + 16 * mt + c, a.M - 1)];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) ws[nt] = *(const f32x4*)(a.wscale + min(n0 + 64 * wc + 16 * nt + 4 * q, a.N - 4));
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[nt][mt][r] *= ws[nt][r] * xs[mt];
-  }
-  if constexpr (is_glu<EPI>) {
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int m = m0 + 128 * wr + 16 * mt + c;
-#pragma unroll
-      for (int nt = 0; nt < 4; nt += 2) store_glu<EPI>(a, acc[nt][mt], acc[nt + 1][mt], m, n0 + 64 * wc + 16 * nt, q);
+    if constexpr (!STAGGER) {
+      for (int t = 0; t < nk; ++t) {
+        const char* st = smem + (t & 1) * STAGE;
+        const int P = 4 * t;
+        // ph0: (m0, n0)
+        read_x(st, 0);
+        read_w(st, 0, wf[0]);
+        issue(K3{}, t + 1);  // unit P + 7
+        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        phase_end();
+        // ph1: (m0, n1)
+        read_w(st, 1, wf[1]);
+        issue(K0{}, t + 2);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        phase_end();
+        // ph2: (m1, n1)
+        read_x(st, 1);
+        issue(K1{}, t + 2);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        phase_end();
+        // ph3: (m1, n0); retire K tile t+1, keep the units issued behind it in flight
+        issue(K2{}, t + 2);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        wait_units_in_flight(max(0, min(3, total_units - 1 - (P + 7))));
+        phase_end();
+      }
+    } else {
+      const bool late = wr == 1;  // wave-uniform
+      if (late) phase_end();
+      for (int t = 0; t < nk; ++t) {
+        const char* st = smem + (t & 1) * STAGE;
+        const int keep = max(0, min(3, total_units - 1 - (4 * t + 7)));
+        read_x(st, 0);
+        read_w(st, 0, wf[0]);
+        issue(K3{}, t + 1);
+        phase_end();
+        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        phase_end();
+        read_w(st, 1, wf[1]);
+        issue(K0{}, t + 2);
+        phase_end();
+        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        phase_end();
+        read_x(st, 1);
+        issue(K1{}, t + 2);
+        phase_end();
+        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        phase_end();
+        issue(K2{}, t + 2);
+        if (late) wait_units_in_flight(keep);
+        phase_end();
+        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        if (!late) wait_units_in_flight(keep);
+        phase_end();
+      }
+      if (!late) phase_end();
     }
-  } else {
-    // Through LDS so that HBM sees whole 128-byte rows: the fragment layout gives a lane 8 bytes of 16 different rows
-    // per store (32 store instructions per wave, 16 partial lines each); staged, a wave stores its 128 x 64 block as
-    // 16 instructions of 8 full rows.  Every wave uses a private 16 KiB of the (now idle) operand stages; the
-    // last phase_end() of the main loop is the barrier that frees them.
-    char* ep = smem + w * 16384;  // [128 rows][128 B], 16-byte chunk p of row r at p ^ (r & 7)
+    // Every wave is past its last fragment read and no DMA is in flight (the last K tile's waits kept 0 units).
+    stamp(1);
+
+    // ---- what the epilogue needs from global memory is fetched BEFORE the next tile's DMAs are issued: while a DMA is in
+    // flight hipcc waits vmcnt(0) at the first use of an ordinary load's result, which would drain the prologue again
+    const int em0 = m0, en0 = n0;  // origin of the finished tile
     bf16x4 bv[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + 64 * wc + 16 * nt + 4 * q;
-      bv[nt] = (a.bias && n < a.N) ? *(const bf16x4*)(a.bias + n) : bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-    }
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    if constexpr (!is_glu<EPI>) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const int ml = 16 * mt + c;
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[nt][mt][r] + bf2f(bv[nt][r]);
-          if constexpr (EPI == EPI_QUICKGELU) v = act_quick_gelu(rbf(v));
-          else if constexpr (EPI == EPI_GELU) v = act_gelu_erf(rbf(v));
-          else if constexpr (EPI == EPI_GELU_TANH) v = act_gelu_tanh(rbf(v));
-          o[r] = f2bf(v);
-        }
-        *(bf16x4*)(ep + ml * 128 + (((2 * nt + (q >> 1)) ^ (ml & 7)) << 4) + (q & 1) * 8) = o;
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own wave's writes are in LDS before any lane reads them
-    __builtin_amdgcn_wave_barrier();
-    const int pch = lane & 7;
-    const int n = n0 + 64 * wc + 8 * pch;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = 8 * i + (lane >> 3);
-      const int m = m0 + 128 * wr + row;
-      bf16x8 v = *(const bf16x8*)(ep + row * 128 + ((pch ^ (row & 7)) << 4));
-      if (ABL == 6 ? (bf2f(v[0]) == 12345.678f) : (m < a.M && n < a.N)) {  // ABL 6: everything but the global stores
-        if constexpr (EPI == EPI_RESIDUAL) {
-          const bf16x8 rs = *(const bf16x8*)(a.res + (size_t)m * a.ldres + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(rs[e]));
-        }
-        bf16x8* dst = (bf16x8*)(a.out + (size_t)m * a.ldo + n);
-        if constexpr (ABL == 7) __builtin_nontemporal_store(v, dst);  // store policies: measured equal to the default one
-        else if constexpr (ABL == 8) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-        else if constexpr (ABL == 9) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
-        else *dst = v;
+        const int n = en0 + 64 * wc + 16 * nt + 4 * q;
+        bv[nt] = (a.bias && n < a.N) ? *(const bf16x4*)(a.bias + n) : bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
       }
     }
+    // residual rows of the finished tile, in the order the store passes consume them.  Two passes' worth (8 loads of a wave)
+    // go out together ahead of the next tile's DMAs, the other two as soon as a pass has consumed its rows, so their latency
+    // passes under the staging work (fetched pass by pass, each pass waited for its own four loads: ~7 us of a 49 us tile of
+    // the K = 1280 projections)
+    bf16x8 rs[2][4];
+    auto load_res = [&](int pass) {
+      const int n = en0 + 64 * wc + 8 * (lane & 7);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = em0 + 128 * wr + 32 * pass + 8 * i + (lane >> 3);
+        rs[pass & 1][i] = *(const bf16x8*)(a.res + (size_t)min(m, a.M - 1) * a.ldres + min(n, a.N - 8));
+      }
+    };
+    constexpr bool kResAhead = EPI == EPI_RESIDUAL && !FP8;  // (the fp8 form keeps 24 scale registers live here: it would spill)
+    if constexpr (kResAhead) {
+      load_res(0);
+      load_res(1);
+    }
+    float xs[8];
+    f32x4 ws[4];
+    if constexpr (FP8) {
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) xs[mt] = a.xscale[min(em0 + 128 * wr + 16 * mt + c, a.M - 1)];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) ws[nt] = *(const f32x4*)(a.wscale + min(en0 + 64 * wc + 16 * nt + 4 * q, a.N - 4));
+    }
+
+    // ---- next tile's prologue: its first K tiles land under this tile's epilogue
+    tile += gridDim.x;
+    const bool more = tile < ntiles;  // workgroup-uniform
+    if (more) {
+      origin_of(tile);
+      set_sources();
+      issue_prologue();
+    }
+
+    // ---- epilogue: lane (c,q) of tile (nt,mt) holds out[em0 + 128wr + 16mt + c][en0 + 64wc + 16nt + 4q .. +3]
+    if constexpr (ABL == 5) {  // no epilogue: the accumulators only have to stay alive
+      float sum = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) sum += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
+      if (sum == 12345.678f) a.out[0] = f2bf(sum);
+    } else {
+      if constexpr (FP8) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nt][mt][r] *= ws[nt][r] * xs[mt];
+      }
+      if constexpr (is_glu<EPI>) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+          const int m = em0 + 128 * wr + 16 * mt + c;
+#pragma unroll
+          for (int nt = 0; nt < 4; nt += 2) store_glu<EPI>(a, acc[nt][mt], acc[nt + 1][mt], m, en0 + 64 * wc + 16 * nt, q);
+        }
+      } else {
+        // Through LDS so that HBM sees whole 128-byte rows: the fragment layout gives a lane 8 bytes of 16 different rows
+        // per store (16 partial lines each); staged, a wave stores its 128 x 64 block as 16 instructions of 8 full rows.
+        // Staging is private to the wave: 32 rows x 128 B at a time (4 passes), 16-byte chunk p of row r at p ^ (r & 7).
+        char* ep = smem + 2 * STAGE + w * 4096;
+        const int pch = lane & 7;
+        const int n = en0 + 64 * wc + 8 * pch;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          if constexpr (EPI == EPI_RESIDUAL && !kResAhead) load_res(pass);
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              const int mt = 2 * pass + mh;
+              const int ml = 16 * mh + c;
+              bf16x4 o;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float v = acc[nt][mt][r] + bf2f(bv[nt][r]);
+                if constexpr (EPI == EPI_QUICKGELU) v = act_quick_gelu(rbf(v));
+                else if constexpr (EPI == EPI_GELU) v = act_gelu_erf(rbf(v));
+                else if constexpr (EPI == EPI_GELU_TANH) v = act_gelu_tanh(rbf(v));
+                o[r] = f2bf(v);
+              }
+              *(bf16x4*)(ep + ml * 128 + (((2 * nt + (q >> 1)) ^ (ml & 7)) << 4) + (q & 1) * 8) = o;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own wave's writes are in LDS before any lane reads them
+          __builtin_amdgcn_wave_barrier();
+          bf16x8 v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + (lane >> 3);
+            v[i] = *(const bf16x8*)(ep + row * 128 + ((pch ^ (row & 7)) << 4));
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and read back before the next pass overwrites them
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row = 32 * pass + 8 * i + (lane >> 3);
+            const int m = em0 + 128 * wr + row;
+            if (ABL == 6 ? (bf2f(v[i][0]) == 12345.678f) : (m < a.M && n < a.N)) {  // ABL 6: everything but the global stores
+              if constexpr (EPI == EPI_RESIDUAL) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = f2bf(bf2f(v[i][e]) + bf2f(rs[pass & 1][i][e]));
+              }
+              bf16x8* dst = (bf16x8*)(a.out + (size_t)m * a.ldo + n);
+              if constexpr (ABL == 7) __builtin_nontemporal_store(v[i], dst);  // store policies: measured equal to the default one
+              else if constexpr (ABL == 8) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v[i]) : "memory");
+              else if constexpr (ABL == 9) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v[i]) : "memory");
+              else *dst = v[i];
+            }
+          }
+          if constexpr (kResAhead)
+            if (pass < 2) load_res(pass + 2);
+        }
+      }
+    }
+    stamp(2);
+    ++tl_i;
+    if (!more) break;
+    // The next tile's K tile 0 must have landed.  In flight, oldest first: its 14 prologue DMAs, then this epilogue's stores.
+    // vmcnt retires in issue order on gfx9-family parts (loads and stores share the one counter; the compiler's own waits rely
+    // on it), so with the 16 stores of a full interior tile behind them "22 outstanding" = K tile 0 landed, 3 units + the stores
+    // still flying — the store drain overlaps the first K tiles as it did when the workgroup simply ended.  Edge tiles skip
+    // stores (fewer operations behind the DMAs): they wait for everything.
+    constexpr bool kStores = ABL != 5 && ABL != 6;  // (ablation builds without the stores)
+    if (kStores && em0 + BM <= a.M && en0 + BN <= a.N) {
+      switch (max(0, min(3, total_units - 4))) {  // units of the prologue allowed to stay in flight (3 unless K < 128)
+        case 3: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+      }
+    } else {
+      wait_units_in_flight(kStores ? 0 : max(0, min(3, total_units - 4)));
+    }
+    phase_end();
   }
+}
+
+// one workgroup per CU (its 160 KiB of LDS admit no second one), each walking tiles b, b + grid, ...
+inline int persistent_grid(const WideArgs& b) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  const int ntiles = b.tilesM * b.tilesN;
+  return ntiles < cus ? ntiles : cus;
 }
 
 template <int EPI, bool STAGGER, bool FP8>
@@ -325,7 +448,7 @@ void launch_one(const WideArgs& b, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     done = true;
   }
-  hipLaunchKernelGGL((gemm_wide256_kernel<EPI, STAGGER, FP8>), dim3(b.tilesM * b.tilesN), dim3(512), LDS_BYTES, st, b);
+  hipLaunchKernelGGL((gemm_wide256_kernel<EPI, STAGGER, FP8>), dim3(persistent_grid(b)), dim3(512), LDS_BYTES, st, b);
 }
 template <int EPI, bool FP8>
 void launch(const WideArgs& a, hipStream_t st) {
@@ -340,7 +463,13 @@ void launch(const WideArgs& a, hipStream_t st) {
                : ablate == 8 ? gemm_wide256_kernel<EPI_LINEAR, true, false, 8>
                              : gemm_wide256_kernel<EPI_LINEAR, true, false, 9>;
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      hipLaunchKernelGGL(k, dim3(b.tilesM * b.tilesN), dim3(512), LDS_BYTES, st, b);
+      hipLaunchKernelGGL(k, dim3(persistent_grid(b)), dim3(512), LDS_BYTES, st, b);
+      return;
+    }
+    if (ablate == 10) {
+      auto k = gemm_wide256_kernel<EPI_LINEAR, true, false, 10>;
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipLaunchKernelGGL(k, dim3(persistent_grid(b)), dim3(512), LDS_BYTES, st, b);
       return;
     }
     if (ablate >= 1 && ablate <= 6) {
@@ -351,7 +480,7 @@ void launch(const WideArgs& a, hipStream_t st) {
                : ablate == 5 ? gemm_wide256_kernel<EPI_LINEAR, true, false, 5>
                              : gemm_wide256_kernel<EPI_LINEAR, true, false, 6>;
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-      hipLaunchKernelGGL(k, dim3(b.tilesM * b.tilesN), dim3(512), LDS_BYTES, st, b);
+      hipLaunchKernelGGL(k, dim3(persistent_grid(b)), dim3(512), LDS_BYTES, st, b);
       return;
     }
   }
@@ -376,6 +505,12 @@ int dispatch(const WideArgs& a, int epi, hipStream_t stream) {
 }  // namespace
 
 int hwocr_gemm_wide256(const WideArgs& a, int epi, hipStream_t stream) { return dispatch<false>(a, epi, stream); }
+
+// timeline stamps of the last HWOCR_GEMM_ABLATE=10 launch: [workgroup][tile slot 0..63][start, loop end, epilogue end, -] ticks of 10 ns
+extern "C" int hwocr_debug_gemm_timeline(unsigned long long* host, int n) {
+  if (!host || n <= 0 || n > TL_MAX) return HWOCR_EINVAL;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timeline), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? HWOCR_OK : HWOCR_ELAUNCH;
+}
 
 // X and W hold E4M3 bytes (ldx / ldw / K in elements = bytes), a.xscale / a.wscale their per-row fp32 scales
 int hwocr_gemm_wide256_fp8(const WideArgs& a, int epi, hipStream_t stream) {

@@ -18,18 +18,23 @@ enum : int {
 };
 template <int EPI> inline constexpr bool is_glu = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
 
+// The activations run once per output element in the GEMM epilogues (128 elements per lane and tile), so their instruction
+// count is tile time: an IEEE fp32 division is ~10 VALU instructions and tanhf ~40; here a sigmoid is exp + rcp (v_exp_f32,
+// v_rcp_f32: 1 ulp each) and tanh is written through it.  Every result is rounded to bf16 (8 significant bits) right after.
+__device__ __forceinline__ float fast_sigmoid(float t) { return __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
 __device__ __forceinline__ float act_quick_gelu(float v) {
   const float t = rbf(1.702f * v);
-  const float s = rbf(1.0f / (1.0f + __expf(-t)));
+  const float s = rbf(fast_sigmoid(t));
   return v * s;
 }
 __device__ __forceinline__ float act_gelu_erf(float v) {
   return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
 }
-__device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }
-// torch's tanh GELU: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float act_silu(float v) { return v * fast_sigmoid(v); }
+// torch's tanh GELU: 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3); 1 + tanh(u) = 2 sigmoid(2u)
 __device__ __forceinline__ float act_gelu_tanh(float v) {
-  return 0.5f * v * (1.0f + tanhf(0.79788456080286535588f * (v + 0.044715f * (v * v * v))));
+  const float u = 0.79788456080286535588f * (v + 0.044715f * (v * v * v));
+  return v * fast_sigmoid(2.0f * u);
 }
 template <int EPI> __device__ __forceinline__ float glu_gate(float g) {
   if constexpr (EPI == EPI_GEGLU) return act_gelu_tanh(g);
@@ -93,15 +98,19 @@ __device__ __forceinline__ void store_glu(const WideArgs& a, const f32x4& g, con
   *(bf16x4*)(a.out + (size_t)m * a.ldo + (n_gate >> 1) + 4 * q) = o;
 }
 
-// tile id of a workgroup: XCD-contiguous chunks, then GROUP row panels swept column-major (L2 reuse of both panels)
-__device__ __forceinline__ void tile_of_block(int tilesM, int tilesN, int group, int& tm, int& tn) {
+// tile of a linear id (ids with equal id % 8 share an XCD when consecutive workgroups are dealt round-robin): XCD-contiguous
+// chunks, then GROUP row panels swept column-major (L2 reuse of both panels)
+__device__ __forceinline__ void tile_of_id(int id, int tilesM, int tilesN, int group, int& tm, int& tn) {
   const int nwg = tilesM * tilesN;
-  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int wg = xcd_remap(id, nwg);
   const int per_group = group * tilesN;
   const int g = wg / per_group, rem = wg - g * per_group;
   const int gm = min(group, tilesM - g * group);
   tm = g * group + rem % gm;
   tn = rem / gm;
+}
+__device__ __forceinline__ void tile_of_block(int tilesM, int tilesN, int group, int& tm, int& tn) {
+  tile_of_id(blockIdx.x, tilesM, tilesN, group, tm, tn);
 }
 
 }  // namespace gemm
@@ -119,5 +128,4 @@ int hwocr_gemm_stream_variant(int Bsz, int N, int K, int epi, int splitk, const 
 // launcher of the 256x256 kernel (gemm256.hip); returns HWOCR_EINVAL when the shape does not qualify
 int hwocr_gemm_wide256(const gemm::WideArgs& a, int epi, hipStream_t stream);
 int hwocr_gemm_wide256_fp8(const gemm::WideArgs& a, int epi, hipStream_t stream);
-// the four-wave structure of the same tile (gemm256x4.hip)
-int hwocr_gemm_wide256x4(const gemm::WideArgs& a, int epi, hipStream_t stream);
+

@@ -28,6 +28,12 @@
 // Later finding (252 rows): the cost is per loop trip and per DMA instruction rather than per byte - the 32-wide-K kernel's
 // skeleton alone (4-byte DMAs, no fragment reads, no MFMA) takes 31 of the 41 us of the 2B gate/up GEMM, about 33 1-KiB DMA
 // instructions per us per CU - hence the 64-wide-K form with 16 row tiles below (gemm_stream_kernel<16, EPI, 2, WT>).
+// Round 2 re-measured the two remaining suspects on the two-row-block form at 252 rows (tools/bench_decode_plan.py, weights cold):
+// smaller stages = a deeper ring (8 / 10 / 12 weight slots instead of 16: 5 / 4 / 4 stages instead of 3) and non-temporal weight
+// DMAs.  2B gate/up 26.5 us with the 3-stage ring against 27.5-28.6 with the deeper ones, 26.5 against 26.5-28.6 with nt; qkv / o /
+// down likewise within +-1 us.  Bytes in flight are not what holds the kernel at ~31 GB/s per CU; the guide's own LDS-DMA ring
+// GEMM (MI355X_MICROARCH.md, rows ring-gemm / ring-vs-splitk: 25 MB of weights x 192 rows in 14.7-19.7 us = 1.3-1.7 TB/s of
+// weights) is slower per weight byte than this kernel (55 MB x 252 rows in 26.5 us = 2.1 TB/s).
 // Epilogues as gemm_skinny: PARTIAL fp32 split-K slabs, LINEAR (+bias), SWIGLU / GEGLU on interleaved gate/up tile pairs.
 #include "gemm_common.cuh"
 #include <cstdlib>
@@ -39,6 +45,13 @@ namespace {
 constexpr int WG_TILES = 16;               // weight tiles per workgroup
 constexpr int WAVES = 16;
 constexpr int WBYTES = WG_TILES * 2048;    // one K tile (64) of 16 weight tiles' fragments
+// stages of the ring of gemm_stream_kernel<MT, ., ., WT>: as many 64-wide K tiles (x tile + WT weight-tile slots) as fit in
+// 160 KiB, at most 6 (wait_dma counts up to 15 outstanding instructions: 3 per K tile and wave)
+constexpr int stream_stages(int MT, int WT) {
+  const int stage = 2 * MT * 1024 + WT * 2048;
+  const int n = (160 * 1024) / stage;
+  return n > 6 ? 6 : n;
+}
 
 __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of this wave's DMA instructions in flight
   switch (pending) {
@@ -55,7 +68,15 @@ __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of t
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
     case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // more than 12 never occurs (<= 3 tiles x 4 instructions)
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // more than 20 never occurs (<= 5 tiles x 4 instructions)
   }
 }
 
@@ -79,7 +100,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
   constexpr int XPW = (XFR + WAVES - 1) / WAVES;    // staged per wave
   constexpr int XBYTES = XFR * 1024;
   constexpr int STAGE = XBYTES + WBYTES;
-  constexpr int NSTAGE = MT == 16 ? (4 * STAGE <= 160 * 1024 ? 4 : 3) : (3 * STAGE <= 160 * 1024 ? 3 : 2);
+  constexpr int NSTAGE = stream_stages(MT, WT);
   static_assert(NSTAGE * STAGE <= 160 * 1024, "ring does not fit in LDS");
   constexpr int DIST = NSTAGE - 1;                  // K tiles in flight ahead of the one being multiplied
   static_assert(MT % MSPLIT == 0 && (MSPLIT == 1 || MSPLIT == 2), "row tiles split evenly over the wave rows");
@@ -354,7 +375,7 @@ void launch256(const StreamArgs& a, dim3 grid, hipStream_t st) {
 template <int MT, int EPI, int MSPLIT, int WT>
 void launch_one(const StreamArgs& a, dim3 grid, hipStream_t st) {
   constexpr int STAGE = 2 * MT * 1024 + WT * 2048;
-  constexpr int LDS = (MT == 16 ? (4 * STAGE <= 160 * 1024 ? 4 : 3) : (3 * STAGE <= 160 * 1024 ? 3 : 2)) * STAGE;
+  constexpr int LDS = stream_stages(MT, WT) * STAGE;
   static bool done = false;
   if (!done) {
     (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<MT, EPI, MSPLIT, WT>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -840,19 +840,3 @@ def test_attn_prefill_hd256_long_reads():
         want = _sdpa_ref(q[s, :n].float().permute(1, 0, 2), k[s, :, :n].float(), v[s, :, :n].float(), False, scale)
         assert_close_bf16(out[s, :n].view(n, Hq, hd), want, ulps=4.0, atol=4e-3, what=f"attn hd256 read {s}")
     assert torch.isfinite(out.float()).all()
-
-
-def test_gemm_wide_four_wave_variant_in_a_child_process():
-    """gemm256x4.hip (the measured, slower alternative structure of the 256x256 GEMM; HWOCR_GEMM_W4 is read once per process)
-    stays parity-green: the wide-GEMM tests again in a child process with the switch on."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HWOCR_GEMM_W4="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_ops_gpu.py"), "-q", "-m", "gpu", "-x",
-                        "-k", "(test_gemm_wide or test_gemm_wide_swiglu or test_gemm_wide_geglu) and not fp8 and not child"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
