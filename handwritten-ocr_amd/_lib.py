@@ -60,7 +60,12 @@ class Vit(C.Structure):
         ("eps", F), ("patch_w", P), ("blocks", C.POINTER(VitBlock)),
         ("merger_ln_w", P), ("merger_ln_b", P), ("merger_fc1_w", P), ("merger_fc1_b", P),
         ("merger_fc2_w", P), ("merger_fc2_b", P), ("rope_cos", P), ("rope_sin", P), ("pixel_lut", P), ("patch_b", P),
-        ("pos_embed", P)]
+        ("pos_embed", P), ("qk_interleaved", I)]
+
+
+class VitSplit(C.Structure):
+    """hwocr_vit_split: destinations and rotary tables of hwocr_gemm_vit_qkv."""
+    _fields_ = [(n, P) for n in ("Q", "K", "VT", "pos_h", "pos_w", "cos_tab", "sin_tab")] + [("heads", I), ("hd", I), ("tok_ld", I)]
 
 
 class VitLayout(C.Structure):
@@ -119,7 +124,8 @@ _HIP_SIGS = {
     "hwocr_patchify": ([P, P, P, I, I, I, I, I, I, I, I, P, P], I),
     "hwocr_layernorm": ([P, P, P, P, I, I, I, I, F, P], I),
     "hwocr_add_rmsnorm": ([P, I, L, I, P, P, I, P, P, I, P, I, I, F, I, P], I),
-    "hwocr_vit_rope_split": ([P, P, P, P, P, P, P, P, I, I, I, I, P], I),
+    "hwocr_vit_rope_split": ([P, P, P, P, P, P, P, P, I, I, I, I, I, P], I),
+    "hwocr_gemm_vit_qkv": ([P, P, P, I, I, I, I, P, P, C.POINTER(VitSplit), P], I),
     "hwocr_mrope_kv_prefill": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, I, I, P], I),
     "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, I, I, I, I, P, P], I),
     "hwocr_embed_splice": ([P, P, P, P, P, I, I, F, P], I),

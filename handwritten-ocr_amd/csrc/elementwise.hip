@@ -279,6 +279,7 @@ struct VitRopeArgs {
   const bf16* qkv; bf16* Q; bf16* K; bf16* VT;
   const int* pos_h; const int* pos_w; const float* cos_tab; const float* sin_tab;
   int tokens, tok_ld, heads, hd; long q_head_stride, vt_head_stride;
+  int interleaved;  // q / k features of a head arrive as rotary pairs side by side: [d0, d0 + hd/2, d1, d1 + hd/2, ...]
 };
 __global__ __launch_bounds__(256) void vit_rope_split_kernel(VitRopeArgs a) {
   __shared__ bf16 s_v[128][72];
@@ -292,8 +293,20 @@ __global__ __launch_bounds__(256) void vit_rope_split_kernel(VitRopeArgs a) {
     const int tt = rem / per_tok, j = rem % per_tok;
     const int tok = t0 + tt;
     if (tok >= a.tokens) continue;
-    const bf16* src = a.qkv + (long)tok * 3 * D + which * D + h * hd + 8 * j;
-    const bf16x8 va = *(const bf16x8*)src, vb = *(const bf16x8*)(src + half);
+    bf16x8 va, vb;  // x1 = features 8j .. 8j+7 of the head, x2 = their partners hd/2 further on
+    if (a.interleaved) {
+      const bf16* src = a.qkv + (long)tok * 3 * D + which * D + h * hd + 16 * j;
+      const bf16x8 c0 = *(const bf16x8*)src, c1 = *(const bf16x8*)(src + 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        va[e] = c0[2 * e]; vb[e] = c0[2 * e + 1];
+        va[4 + e] = c1[2 * e]; vb[4 + e] = c1[2 * e + 1];
+      }
+    } else {
+      const bf16* src = a.qkv + (long)tok * 3 * D + which * D + h * hd + 8 * j;
+      va = *(const bf16x8*)src;
+      vb = *(const bf16x8*)(src + half);
+    }
     const int ph = a.pos_h[tok], pw = a.pos_w[tok];
     bf16x8 oa, ob;
 #pragma unroll
@@ -690,11 +703,11 @@ extern "C" int hwocr_add_rmsnorm(const float* slabs, int nslab, long slab_stride
 
 extern "C" int hwocr_vit_rope_split(const void* qkv, void* Q, void* K, void* VT, const int* pos_h, const int* pos_w,
                                     const float* cos_tab, const float* sin_tab, int tokens, int tok_ld, int heads,
-                                    int hd, hipStream_t stream) {
+                                    int hd, int interleaved, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (tokens <= 0 || tok_ld % 64 || tok_ld < tokens || hd % 16 || hd > 128) return HWOCR_EINVAL;
   VitRopeArgs a{(const bf16*)qkv, (bf16*)Q, (bf16*)K, (bf16*)VT, pos_h, pos_w, cos_tab, sin_tab,
-                tokens, tok_ld, heads, hd, (long)tok_ld * hd, (long)hd * tok_ld};
+                tokens, tok_ld, heads, hd, (long)tok_ld * hd, (long)hd * tok_ld, interleaved ? 1 : 0};
   hipLaunchKernelGGL(vit_rope_split_kernel, dim3((tok_ld + 63) / 64, heads), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }

@@ -340,7 +340,100 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[nt][mt][r] *= ws[nt][r] * xs[mt];
       }
-      if constexpr (is_glu<EPI>) {
+      if constexpr (EPI == EPI_VIT_QKV) {
+        // Vision QKV projection with the rotary embedding, the head split and the V transpose folded in (what
+        // vit_rope_split_kernel does to a [tokens][3 DH] intermediate).  DH % 256 == 0: a tile is all q, all k or all v.
+        const hwocr_vit_split& vs = a.vs;
+        const int hd = vs.hd, half = hd >> 1, quarter = hd >> 2, DH = vs.heads * hd;
+        const int sec = en0 / DH, nsec = en0 - sec * DH;  // section (0 q, 1 k, 2 v) and the tile's first column inside it
+        char* ep = smem + 2 * STAGE + w * 4096;
+        if (sec < 2) {
+          // q / k columns come as rotary pairs side by side (the weight rows were interleaved when they were bound), so a
+          // lane's 4 consecutive columns of an MFMA tile are two whole pairs: columns 16nt + 4q + {0,1} = pair p (x1, x2),
+          // {2,3} = pair p + 1, p = 8nt + 2q of the wave's 32 pairs; pair P of the section = head P / half, feature P % half.
+          bf16* dst = (bf16*)(sec ? vs.K : vs.Q);
+          const int P0 = (nsec + 64 * wc) >> 1;
+          int fi[4];  // feature index i of the lane's first pair in every n-tile (the second is i + 1, same head, same axis)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) fi[nt] = (P0 + 8 * nt + 2 * q) % half;
+          // store side: chunk pch of a staged row = 8 features of group g = pch & 3, low (x1) half for pch < 4, high for pch >= 4
+          const int pch = lane & 7;
+          const int Pg = P0 + 8 * (pch & 3);
+          const long dcol = (long)(Pg / half) * vs.tok_ld * hd + (Pg % half) + (pch >= 4 ? half : 0);
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+              const int mt = 2 * pass + mh, ml = 16 * mh + c;
+              const int mc = min(em0 + 128 * wr + 16 * mt + c, a.M - 1);
+              const int ph = vs.pos_h[mc], pw = vs.pos_w[mc];
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) {
+                const int i = fi[nt];
+                const int tab = (i < quarter ? ph * quarter + i : pw * quarter + i - quarter);
+                const f32x2 cs = *(const f32x2*)(vs.cos_tab + tab), sn = *(const f32x2*)(vs.sin_tab + tab);
+                float x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = rbf(acc[nt][mt][r] + bf2f(bv[nt][r]));
+                bf16x2 lo, hi;  // fp32 products and sum, one rounding (HF apply_rotary_pos_emb_vision computes in float)
+                lo[0] = f2bf(__fadd_rn(__fmul_rn(x[0], cs[0]), __fmul_rn(-x[1], sn[0])));
+                hi[0] = f2bf(__fadd_rn(__fmul_rn(x[1], cs[0]), __fmul_rn(x[0], sn[0])));
+                lo[1] = f2bf(__fadd_rn(__fmul_rn(x[2], cs[1]), __fmul_rn(-x[3], sn[1])));
+                hi[1] = f2bf(__fadd_rn(__fmul_rn(x[3], cs[1]), __fmul_rn(x[2], sn[1])));
+                *(bf16x2*)(ep + ml * 128 + ((nt ^ (ml & 7)) << 4) + q * 4) = lo;
+                *(bf16x2*)(ep + ml * 128 + (((4 + nt) ^ (ml & 7)) << 4) + q * 4) = hi;
+              }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            bf16x8 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int row = 8 * i + (lane >> 3);
+              v[i] = *(const bf16x8*)(ep + row * 128 + ((pch ^ (row & 7)) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int m = em0 + 128 * wr + 32 * pass + 8 * i + (lane >> 3);
+              if (m < a.M) *(bf16x8*)(dst + dcol + (long)m * hd) = v[i];
+            }
+          }
+        } else {
+          // v columns: transposed through LDS, 16 features x the wave's 128 rows per pass, so that every feature leaves as
+          // 256 contiguous bytes of V^T.  Feature f of the pass sits at f * 256 B; its dword (row pair) j at j ^ (8 (f/4)).
+          bf16* dst = (bf16*)vs.VT;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+              const int ml = 16 * mt + c;
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                *(bf16*)(ep + (4 * q + r) * 256 + (((ml >> 1) ^ (q << 3)) << 2) + (ml & 1) * 2) = f2bf(acc[nt][mt][r] + bf2f(bv[nt][r]));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            bf16x8 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int id = 64 * i + lane, f = id >> 4, ch = id & 15;
+              v[i] = *(const bf16x8*)(ep + f * 256 + ((ch ^ (2 * ((f >> 2) & 3))) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int id = 64 * i + lane, f = id >> 4, ch = id & 15;
+              const int n = nsec + 64 * wc + 16 * nt + f;       // feature of the v section
+              const int row0 = em0 + 128 * wr + 8 * ch;
+              if (row0 + 8 <= vs.tok_ld)
+                *(bf16x8*)(dst + ((long)(n / hd) * hd + n % hd) * vs.tok_ld + row0) = v[i];
+            }
+          }
+        }
+      } else if constexpr (is_glu<EPI>) {
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
           const int m = em0 + 128 * wr + 16 * mt + c;
@@ -497,6 +590,7 @@ int dispatch(const WideArgs& a, int epi, hipStream_t stream) {
     case EPI_SWIGLU: launch<EPI_SWIGLU, FP8>(a, stream); break;
     case EPI_GELU_TANH: launch<EPI_GELU_TANH, FP8>(a, stream); break;
     case EPI_GEGLU: launch<EPI_GEGLU, FP8>(a, stream); break;
+    case EPI_VIT_QKV: launch<EPI_VIT_QKV, FP8>(a, stream); break;
     default: return HWOCR_EINVAL;
   }
   return hwocr_launch_status();
@@ -516,4 +610,18 @@ extern "C" int hwocr_debug_gemm_timeline(unsigned long long* host, int n) {
 int hwocr_gemm_wide256_fp8(const WideArgs& a, int epi, hipStream_t stream) {
   if (!a.xscale || !a.wscale || (a.K % 128) || (a.ldx % 16) || (a.ldw % 16) || a.N < 4) return HWOCR_EINVAL;
   return dispatch<true>(a, epi, stream);
+}
+
+// QKV projection of a vision block with rotary + head split + V transpose in the epilogue (hwocr.h)
+extern "C" int hwocr_gemm_vit_qkv(const void* X, const void* W, const void* bias, int M, int K, int ldx, int ldw,
+                                  const float* xscale, const float* wscale, const hwocr_vit_split* sp, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!X || !W || !sp || !sp->Q || !sp->K || !sp->VT || !sp->pos_h || !sp->pos_w || !sp->cos_tab || !sp->sin_tab) return HWOCR_EINVAL;
+  const bool fp8 = xscale != nullptr || wscale != nullptr;
+  if (fp8 && (!xscale || !wscale)) return HWOCR_EINVAL;
+  if (M <= 0 || K <= 0 || sp->heads <= 0 || !vit_qkv_fusable(M, sp->heads, sp->hd) || sp->tok_ld < M || (sp->tok_ld % 64)) return HWOCR_EINVAL;
+  if (fp8 ? ((K % 128) || (ldx % 16) || (ldw % 16)) : ((K % BK) || (ldx % 8) || (ldw % 8))) return HWOCR_EINVAL;
+  WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, nullptr, nullptr, M, 3 * sp->heads * sp->hd, K, ldx, ldw, 0, 0, 0, 0,
+             xscale, wscale, *sp};
+  return fp8 ? dispatch<true>(a, EPI_VIT_QKV, stream) : dispatch<false>(a, EPI_VIT_QKV, stream);
 }

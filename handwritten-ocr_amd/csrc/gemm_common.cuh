@@ -14,7 +14,8 @@ enum : int {
   EPI_SWIGLU = HWOCR_EPI_SWIGLU,        // rows interleaved [16 gate][16 up]: bf16(bf16(silu(g)) * u)
   EPI_PARTIAL = HWOCR_EPI_PARTIAL,      // fp32 split-K slab (skinny only)
   EPI_GELU_TANH = HWOCR_EPI_GELU_TANH,  // tanh-approximated GELU of bf16(acc + bias)
-  EPI_GEGLU = HWOCR_EPI_GEGLU           // as EPI_SWIGLU with the tanh GELU on the gate
+  EPI_GEGLU = HWOCR_EPI_GEGLU,          // as EPI_SWIGLU with the tanh GELU on the gate
+  EPI_VIT_QKV = 8                       // 256x256 kernel only (hwocr_gemm_vit_qkv): bias, vision rotary, head split, V transposed
 };
 template <int EPI> inline constexpr bool is_glu = EPI == EPI_SWIGLU || EPI == EPI_GEGLU;
 
@@ -46,6 +47,7 @@ struct WideArgs {
   int M, N, K, ldx, ldw, ldo, ldres, tilesM, tilesN;
   const float* xscale = nullptr;  // fp8 operands only (gemm256.hip): one scale per activation row / weight row
   const float* wscale = nullptr;
+  hwocr_vit_split vs = {};        // EPI_VIT_QKV only: where the rotated / split / transposed result goes
 };
 
 // One 16x16 MFMA tile whose A operand was the weight tile: the lane holds out[m][n .. n+3] (4 consecutive features).
@@ -125,6 +127,11 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream);
 // the kernel instance hwocr_gemm_stream would run for this shape (static string), without launching anything
 int hwocr_gemm_stream_variant(int Bsz, int N, int K, int epi, int splitk, const char** name);
 
+// the fused vision QKV form is taken when the attention width is whole 256-wide tiles (no tile mixes q, k and v), the rotary
+// pairs of a head fall into 16-byte pieces and there are enough rows for the 256x256 kernel
+inline bool vit_qkv_fusable(int M, int heads, int hd) {
+  return M >= 1024 && (heads * hd) % 256 == 0 && hd % 16 == 0 && hd <= 128;
+}
 // launcher of the 256x256 kernel (gemm256.hip); returns HWOCR_EINVAL when the shape does not qualify
 int hwocr_gemm_wide256(const gemm::WideArgs& a, int epi, hipStream_t stream);
 int hwocr_gemm_wide256_fp8(const gemm::WideArgs& a, int epi, hipStream_t stream);

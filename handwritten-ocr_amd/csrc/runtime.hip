@@ -9,6 +9,7 @@
 #include "common.cuh"
 #include "hwocr.h"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CHECK(call)                \
@@ -20,6 +21,9 @@
 namespace {
 inline bf16* B(void* p) { return (bf16*)p; }
 inline const bf16* B(const void* p) { return (const bf16*)p; }
+inline bool hwocr_vit_qkv_fusable(int M, int heads, int hd) {  // == gemm::vit_qkv_fusable (gemm_common.cuh)
+  return M >= 1024 && (heads * hd) % 256 == 0 && hd % 16 == 0 && hd <= 128;
+}
 inline int pick_splitk(int K, int N, int want_wgs) {
   const int chunks = (K + 255) / 256;
   const int tiles = (N + 31) / 32;  // gemm_skinny's small-N configuration: 32 weight rows per workgroup
@@ -107,14 +111,24 @@ extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, con
                           HWOCR_EPI_LINEAR, st));
   }
   const float scale = 1.0f / sqrtf((float)(D / m->heads));
+  static const bool fuse_env = [] { const char* e = getenv("HWOCR_VIT_FUSE_QKV"); return !e || atoi(e) != 0; }();
+  const bool fuse_qkv = fuse_env && m->qk_interleaved && (rows % 64) == 0 && hwocr_vit_qkv_fusable(rows, m->heads, hd);
   for (int l = 0; l < m->depth; ++l) {
     const hwocr_vit_block& b = m->blocks[l];
     const bool q1 = runs_fp8(b.qkv8, ws->q8, ws->q8s, D), q2 = runs_fp8(b.fc18, ws->q8, ws->q8s, D);
     CHECK(q1 ? norm8(b.ln1_w, b.ln1_b) : norm(b.ln1_w, b.ln1_b));
-    CHECK(wide(ws->xn, b.qkv_w, b.qkv8, ws->q8, ws->q8s, b.qkv_b, nullptr, ws->qkv, rows, 3 * DH, D, 3 * DH, 0,
-               HWOCR_EPI_LINEAR, st, q1));
-    CHECK(hwocr_vit_rope_split(ws->qkv, ws->q, ws->k, ws->vt, lay->pos_h, lay->pos_w, m->rope_cos, m->rope_sin, rows,
-                               rows, m->heads, hd, st));
+    if (fuse_qkv) {  // rotary + head split + V transpose in the GEMM's epilogue: the [rows][3 DH] intermediate never exists
+      const hwocr_vit_split sp{ws->q, ws->k, ws->vt, lay->pos_h, lay->pos_w, m->rope_cos, m->rope_sin, m->heads, hd, rows};
+      if (q1)
+        CHECK(hwocr_gemm_vit_qkv(ws->q8, b.qkv8.w, b.qkv_b, rows, D, D, D, ws->q8s, b.qkv8.scale, &sp, st));
+      else
+        CHECK(hwocr_gemm_vit_qkv(ws->xn, b.qkv_w, b.qkv_b, rows, D, D, D, nullptr, nullptr, &sp, st));
+    } else {
+      CHECK(wide(ws->xn, b.qkv_w, b.qkv8, ws->q8, ws->q8s, b.qkv_b, nullptr, ws->qkv, rows, 3 * DH, D, 3 * DH, 0,
+                 HWOCR_EPI_LINEAR, st, q1));
+      CHECK(hwocr_vit_rope_split(ws->qkv, ws->q, ws->k, ws->vt, lay->pos_h, lay->pos_w, m->rope_cos, m->rope_sin, rows,
+                                 rows, m->heads, hd, m->qk_interleaved, st));
+    }
     if (v25 && b.windowed && lay->nwin > 0) {
       CHECK(hwocr_attn_varlen(ws->q, ws->k, ws->vt, ws->attn, lay->win_off, lay->win_lens, lay->nwin, m->heads, hd,
                               lay->max_win, (long)rows * hd, hd, (long)rows * hd, hd, (long)hd * rows, rows, DH, scale,

@@ -343,6 +343,15 @@ def _ceil(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def interleave_rotary_pairs(t: torch.Tensor, heads: int, hd: int) -> torch.Tensor:
+    """Rows of a q or k projection ([heads * hd, ...], or its bias [heads * hd]) reordered inside every head so that the two
+    features a rotary pair is made of (d, d + hd/2) sit side by side: [d0, d0 + hd/2, d1, d1 + hd/2, ...].  The QKV GEMM of
+    the vision tower rotates in its epilogue, where a lane owns 4 consecutive output features (hwocr_gemm_vit_qkv)."""
+    tail = tuple(t.shape[1:])
+    v = t.reshape((heads, 2, hd // 2) + tail)
+    return v.transpose(1, 2).reshape((heads * hd,) + tail).contiguous()
+
+
 def pick_attn_splits(reads: int, kv_heads: int) -> int:
     """Context splits of the decode attention: one 8-wave workgroup per (read, kv head) once those alone fill the chip,
     else 4-wave workgroups over 2..16 context splits + a merge launch."""
@@ -472,8 +481,9 @@ class ReadEngine:
         blocks = (_lib.VitBlock * c.depth)()
         for l in range(c.depth):
             b = f"{v}encoder.layers.{l}."
-            qkv_w = torch.cat([pad_heads_rows(sd[b + f"self_attn.{n}_proj.weight"]) for n in "qkv"], dim=0)
-            qkv_b = torch.cat([pad_heads_rows(sd[b + f"self_attn.{n}_proj.bias"]) for n in "qkv"], dim=0)
+            il = lambda t, n: interleave_rotary_pairs(t, Hn, hp) if n in "qk" else t  # noqa: E731  (pairs of the padded head)
+            qkv_w = torch.cat([il(pad_heads_rows(sd[b + f"self_attn.{n}_proj.weight"]), n) for n in "qkv"], dim=0)
+            qkv_b = torch.cat([il(pad_heads_rows(sd[b + f"self_attn.{n}_proj.bias"]), n) for n in "qkv"], dim=0)
             ow = sd[b + "self_attn.out_proj.weight"].to(dev, bf)                        # [D][Hn*hd]
             proj_w = torch.zeros(D, Hn, hp, dtype=bf, device=dev)
             proj_w[:, :, :hd] = ow.reshape(D, Hn, hd)
@@ -500,7 +510,7 @@ class ReadEngine:
                             merger_fc2_b=P(self._t(sd["model.multi_modal_projector.linear.bias"])),
                             rope_cos=P(self.vit_cos), rope_sin=P(self.vit_sin), pixel_lut=P(self.lut),
                             patch_b=P(self._t(sd[v + "embeddings.patch_embedding.bias"])),
-                            pos_embed=P(self._t(sd[v + "embeddings.position_embedding.weight"])))
+                            pos_embed=P(self._t(sd[v + "embeddings.position_embedding.weight"])), qk_interleaved=1)
         self._keep.append(blocks)
 
     def _bind_vision_qwen(self, sd: dict) -> None:
@@ -521,7 +531,12 @@ class ReadEngine:
                   ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias"))
             bound = {}
             for fld, key in common + (() if v25 else v2):
-                bound[fld] = self._t(sd[b + key])
+                t = sd[b + key]
+                if fld in ("qkv_w", "qkv_b"):  # q and k thirds: rotary pairs side by side (hwocr_vit.qk_interleaved)
+                    Dq = t.shape[0] // 3
+                    t = torch.cat([interleave_rotary_pairs(t[:Dq], c.num_heads, c.vit_hd),
+                                   interleave_rotary_pairs(t[Dq: 2 * Dq], c.num_heads, c.vit_hd), t[2 * Dq:]], dim=0)
+                bound[fld] = self._t(t)
                 setattr(blocks[l], fld, P(bound[fld]))
             if v25:
                 # gate/up (+ biases) zero-padded to mlp_dim rows and interleaved in 16-row tiles for the SwiGLU epilogue;
@@ -563,7 +578,7 @@ class ReadEngine:
                             merger_ln_b=None if v25 else P(self._t(sd[v + "merger.ln_q.bias"])),
                             merger_fc1_w=P(self._t(sd[v + "merger.mlp.0.weight"])), merger_fc1_b=P(self._t(sd[v + "merger.mlp.0.bias"])),
                             merger_fc2_w=P(self._t(sd[v + "merger.mlp.2.weight"])), merger_fc2_b=P(self._t(sd[v + "merger.mlp.2.bias"])),
-                            rope_cos=P(self.vit_cos), rope_sin=P(self.vit_sin), pixel_lut=P(self.lut))
+                            rope_cos=P(self.vit_cos), rope_sin=P(self.vit_sin), pixel_lut=P(self.lut), qk_interleaved=1)
         self._keep.append(blocks)
 
     def _bind_decoder(self, sd: dict) -> None:

@@ -120,9 +120,28 @@ int hwocr_add_rmsnorm(const float* slabs, int nslab, long slab_stride, int ld_sl
                       int ldh, const void* w, void* out, int ldo, const int* row_index, int rows, int D, float eps,
                       int gemma, hwocr_stream_t stream);
 
+/* Vision rotary + head split (HF modeling_qwen2_vl.py:239-248, :375-400): qkv [tokens][3][heads][hd] -> Q, K
+ * [heads][tok_ld][hd] rotated (fp32 math on the bf16 values, one rounding) and V^T [heads][hd][tok_ld].  interleaved != 0: the
+ * q / k features of a head arrive as rotary pairs side by side, [d0, d0 + hd/2, d1, d1 + hd/2, ...] — the row order
+ * hwocr_gemm_vit_qkv wants of the QKV weight (hwocr_vit.qk_interleaved); the outputs are in the true feature order either way. */
 int hwocr_vit_rope_split(const void* qkv, void* Q, void* K, void* VT, const int* pos_h, const int* pos_w,
                          const float* cos_tab, const float* sin_tab, int tokens, int tok_ld, int heads, int hd,
-                         hwocr_stream_t stream);
+                         int interleaved, hwocr_stream_t stream);
+
+/* The QKV projection of a vision block with hwocr_vit_rope_split folded into its epilogue: out = X . W^T + bias with W
+ * [3 * heads * hd][K] whose q / k rows are pair-interleaved per head (above); every 256 x 256 output tile is rounded to bf16,
+ * rotated / transposed in registers + LDS and stored straight into Q, K, V^T — the [tokens][3 * heads * hd] intermediate
+ * never exists.  Bit-identical to hwocr_gemm_wide + hwocr_vit_rope_split(interleaved = 1).  xscale / wscale both non-NULL: X
+ * and W hold E4M3 bytes with per-row scales (hwocr_gemm_wide_fp8).  Returns HWOCR_EINVAL unless M >= 1024,
+ * heads * hd % 256 == 0 and hd % 16 == 0 (the caller then runs the two separate calls). */
+typedef struct {
+  void *Q, *K, *VT;
+  const int *pos_h, *pos_w;        /* [tokens] */
+  const float *cos_tab, *sin_tab;  /* fp32 [positions][hd / 4] */
+  int heads, hd, tok_ld;           /* tok_ld: row pitch of Q / K (in tokens) and of V^T (in elements), >= M, % 64 == 0 */
+} hwocr_vit_split;
+int hwocr_gemm_vit_qkv(const void* X, const void* W, const void* bias, int M, int K, int ldx, int ldw, const float* xscale,
+                       const float* wscale, const hwocr_vit_split* split, hwocr_stream_t stream);
 
 /* rows are laid out [nseq][rows_per_seq]; row r belongs to read r / rows_per_seq (K, VT point at the first read's
  * cache), cache slot r % rows_per_seq.  head_dim 128 or 256; rope tables [maxpos][head_dim/2]; sec0 >= head_dim/2 turns
@@ -184,6 +203,7 @@ typedef struct {
   const float *rope_cos, *rope_sin; /* fp32 [maxpos][head_dim/4] */
   const void* pixel_lut;            /* bf16 [3][256] */
   const void *patch_b, *pos_embed;  /* SIGLIP: conv bias [dim], learned positions [patches][dim]; else NULL */
+  int qk_interleaved;               /* the q / k rows of every block's qkv_w / qkv_b (and qkv8) are pair-interleaved per head */
 } hwocr_vit;
 
 typedef struct { /* all device buffers, rows = nimg * rows_per_img_ld; vt holds 64 elements of slack past rows*dim */

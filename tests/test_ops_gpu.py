@@ -476,13 +476,24 @@ def _vit_pos(gh, gw, merge):
     return f(hp), f(wp)
 
 
+def _interleave_qk(qkv, heads, hd):
+    """[rows][3][heads][hd] with the q / k features of every head as rotary pairs side by side (engine.interleave_rotary_pairs
+    applied to the output features)."""
+    rows = qkv.shape[0]
+    v = qkv.view(rows, 3, heads, 2, hd // 2)
+    il = v[:, :2].transpose(3, 4).reshape(rows, 2, heads, hd)
+    return torch.cat([il, qkv.view(rows, 3, heads, hd)[:, 2:]], dim=1).reshape(rows, 3 * heads * hd).contiguous()
+
+
+@pytest.mark.parametrize("interleaved", [0, 1])
 @pytest.mark.parametrize("hd,heads", [(80, 4), (32, 2)])
-def test_vit_rope_split(hd, heads):
+def test_vit_rope_split(hd, heads, interleaved):
     gh, gw = 8, 12
     P = gh * gw
     tok_ld = 128
     D = heads * hd
     qkv = randbf(tok_ld, 3 * D, seed=27)
+    qkv_in = _interleave_qk(qkv, heads, hd) if interleaved else qkv  # same values, pair-interleaved arrival order
     ph, pw = _vit_pos(gh, gw, 2)
     pos_h = torch.zeros(tok_ld, dtype=torch.int32)
     pos_w = torch.zeros(tok_ld, dtype=torch.int32)
@@ -495,8 +506,8 @@ def test_vit_rope_split(hd, heads):
     K = torch.zeros_like(Q)
     VT = torch.full((heads, hd, tok_ld), float("nan"), dtype=torch.bfloat16, device=DEV)
     ph_d, pw_d, cos_d, sin_d = pos_h.to(DEV), pos_w.to(DEV), cos_t.to(DEV), sin_t.to(DEV)
-    rc = lib().hwocr_vit_rope_split(p(qkv), p(Q), p(K), p(VT), p(ph_d), p(pw_d), p(cos_d), p(sin_d), P, tok_ld, heads,
-                                    hd, st())
+    rc = lib().hwocr_vit_rope_split(p(qkv_in), p(Q), p(K), p(VT), p(ph_d), p(pw_d), p(cos_d), p(sin_d), P, tok_ld, heads,
+                                    hd, interleaved, st())
     assert rc == 0
     sync()
     x = qkv[:P].float().cpu().view(P, 3, heads, hd)
@@ -510,6 +521,87 @@ def test_vit_rope_split(hd, heads):
     assert torch.equal(VT[:, :, :P].cpu(), qkv[:P].cpu().view(P, 3, heads, hd)[:, 2].permute(1, 2, 0))
     assert (VT[:, :, P:].cpu() == 0).all()
     assert quarter * 4 == hd
+
+
+# (M, K, heads, hd): the page-read shape of the Qwen towers and SigLIP-padded (16 x 80), ragged M (edge tiles), other head sizes
+@pytest.mark.parametrize("fp8", [0, 1])
+@pytest.mark.parametrize("M,K,heads,hd", [(5184, 1280, 16, 80), (1300, 256, 16, 80), (1088, 128, 8, 64), (2048, 192, 2, 128),
+                                          (1024, 128, 16, 32)])
+def test_gemm_vit_qkv_equals_gemm_then_rope_split(M, K, heads, hd, fp8):
+    """hwocr_gemm_vit_qkv (rotary + head split + V transpose in the GEMM epilogue) against the two kernels it replaces,
+    bit for bit, and against the fp32 restatement of HF's vision attention front end (modeling_qwen2_vl.py:239-248, :375-400)."""
+    if fp8 and K % 128:
+        pytest.skip("fp8 operands need K % 128 == 0")
+    DH = heads * hd
+    tok_ld = (M + 63) // 64 * 64
+    x = randbf(M, K, seed=51)
+    w = randbf(3 * DH, K, scale=K ** -0.5, seed=52)             # rows already in the pair-interleaved order
+    bias = randbf(3 * DH, scale=0.5, seed=53)
+    g = torch.Generator().manual_seed(3)
+    pos_h = torch.randint(0, 60, (tok_ld,), generator=g, dtype=torch.int32)
+    pos_w = torch.randint(0, 60, (tok_ld,), generator=g, dtype=torch.int32)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd // 2, 2, dtype=torch.float) / (hd // 2)))
+    tab = torch.arange(64, dtype=torch.float).unsqueeze(-1) * inv
+    cos_d, sin_d, ph_d, pw_d = tab.cos().contiguous().to(DEV), tab.sin().contiguous().to(DEV), pos_h.to(DEV), pos_w.to(DEV)
+
+    def bufs():
+        return (torch.full((heads, tok_ld, hd), float("nan"), dtype=torch.bfloat16, device=DEV),
+                torch.full((heads, tok_ld, hd), float("nan"), dtype=torch.bfloat16, device=DEV),
+                torch.full((heads, hd, tok_ld), float("nan"), dtype=torch.bfloat16, device=DEV))
+
+    from handwritten_ocr_amd import _lib
+    if fp8:
+        x8, xs = torch.empty(M, K, dtype=torch.uint8, device=DEV), torch.empty(M, dtype=torch.float32, device=DEV)
+        w8, wsc = torch.empty(3 * DH, K, dtype=torch.uint8, device=DEV), torch.empty(3 * DH, dtype=torch.float32, device=DEV)
+        assert lib().hwocr_quant_rows_fp8(p(x), p(x8), p(xs), M, K, K, K, st()) == 0
+        assert lib().hwocr_quant_rows_fp8(p(w), p(w8), p(wsc), 3 * DH, K, K, K, st()) == 0
+    # the two separate kernels
+    qkv = torch.empty(M, 3 * DH, dtype=torch.bfloat16, device=DEV)
+    if fp8:
+        assert lib().hwocr_gemm_wide_fp8(p(x8), p(xs), p(w8), p(wsc), p(bias), None, p(qkv), M, 3 * DH, K, K, K, 3 * DH, 0, 0, st()) == 0
+    else:
+        assert lib().hwocr_gemm_wide(p(x), p(w), p(bias), None, p(qkv), M, 3 * DH, K, K, K, 3 * DH, 0, 0, st()) == 0
+    Q0, K0, V0 = bufs()
+    assert lib().hwocr_vit_rope_split(p(qkv), p(Q0), p(K0), p(V0), p(ph_d), p(pw_d), p(cos_d), p(sin_d), M, tok_ld, heads, hd, 1,
+                                      st()) == 0
+    # the fused one
+    Q1, K1, V1 = bufs()
+    sp = _lib.VitSplit(Q=p(Q1), K=p(K1), VT=p(V1), pos_h=p(ph_d), pos_w=p(pw_d), cos_tab=p(cos_d), sin_tab=p(sin_d), heads=heads,
+                       hd=hd, tok_ld=tok_ld)
+    import ctypes as C
+    rc = lib().hwocr_gemm_vit_qkv(p(x8) if fp8 else p(x), p(w8) if fp8 else p(w), p(bias), M, K, K, K, p(xs) if fp8 else None,
+                                  p(wsc) if fp8 else None, C.byref(sp), st())
+    assert rc == 0
+    sync()
+    assert torch.equal(Q1[:, :M], Q0[:, :M]) and torch.equal(K1[:, :M], K0[:, :M]), "fused rotary differs from gemm + rope_split"
+    assert torch.equal(V1[:, :, :M], V0[:, :, :M]), "fused V transpose differs from gemm + rope_split"
+    if fp8:
+        return  # the bf16 form below pins the arithmetic; the fp8 GEMM has its own exact test
+    # fp32 restatement: de-interleave the features, rotate as HF does
+    acc = rbf(x.float() @ w.float().t() + bias.float()).cpu().view(M, 3, heads, hd // 2, 2)
+    qk = acc[:, :2].transpose(3, 4).reshape(M, 2, heads, hd)       # true feature order (d, then d + hd/2)
+    rot = torch.cat([tab[pos_h[:M].long()], tab[pos_w[:M].long()]], -1)
+    emb = torch.cat([rot, rot], -1)
+    cos, sin = emb.cos().unsqueeze(1), emb.sin().unsqueeze(1)
+    rh = lambda t: torch.cat([-t[..., hd // 2:], t[..., : hd // 2]], -1)
+    for which, got in ((0, Q1), (1, K1)):
+        want = qk[:, which] * cos + rh(qk[:, which]) * sin
+        # the bf16 rounding of acc + bias (a rounding point of the reference too) can flip by one ulp with the accumulation
+        # order: 2 ulps of the larger of the pair
+        mag = qk[:, which].abs() + rh(qk[:, which]).abs()
+        assert_close_bf16(got[:, :M].cpu().permute(1, 0, 2), want, ulps=2.0, atol=2e-3, what=f"fused vit rope {which}", mag=mag)
+    vwant = rbf(x.float() @ w.float().t() + bias.float()).cpu()[:, 2 * DH:].view(M, heads, hd).permute(1, 2, 0)
+    assert_close_bf16(V1[:, :, :M].cpu(), vwant, ulps=1.0, atol=2e-3, what="fused V^T")
+
+
+def test_gemm_vit_qkv_rejects_shapes_it_cannot_fuse():
+    from handwritten_ocr_amd import _lib
+    import ctypes as C
+    x = randbf(64, 64)
+    sp = _lib.VitSplit(Q=p(x), K=p(x), VT=p(x), pos_h=p(x), pos_w=p(x), cos_tab=p(x), sin_tab=p(x), heads=6, hd=64, tok_ld=1024)
+    assert lib().hwocr_gemm_vit_qkv(p(x), p(x), None, 1024, 64, 64, 64, None, None, C.byref(sp), st()) == 1   # 6 x 64 is not whole tiles
+    sp.heads = 8
+    assert lib().hwocr_gemm_vit_qkv(p(x), p(x), None, 512, 64, 64, 64, None, None, C.byref(sp), st()) == 1    # too few rows
 
 
 def _mrope_ref(x, pos3, cos_tab, sin_tab, sec0, sec1):
