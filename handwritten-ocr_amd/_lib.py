@@ -120,6 +120,7 @@ _HIP_SIGS = {
     "hwocr_tile_weights": ([P, P, I, I, I, P], I),
     "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, I, P], I),
     "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, P], I),
+    "hwocr_attn_decode_qkv": ([P, I, L, P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, I, I, P, P], I),
     "hwocr_attn_varlen": ([P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, F, P], I),
     "hwocr_patchify": ([P, P, P, I, I, I, I, I, I, I, I, P, P], I),
     "hwocr_layernorm": ([P, P, P, P, I, I, I, I, F, P], I),

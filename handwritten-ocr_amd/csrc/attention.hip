@@ -722,6 +722,12 @@ struct DecodeArgs {
   int Hq, Hkv, G, nsplit;
   float scale_log2;
   int kv_tiled;
+  // fused QKV finish (hwocr_attn_decode_qkv; slabs == nullptr: Q, K, V^T were prepared by decode_qkv_finish_kernel): this
+  // step's q / k / v arrive as the split-K slabs of the QKV projection
+  const float* slabs = nullptr; int nslab = 0; long slab_stride = 0;
+  const bf16* bias = nullptr; const int* rope_delta = nullptr; const bf16* cos_tab = nullptr; const bf16* sin_tab = nullptr;
+  int ctx = 0, max_pos = 0; int* status = nullptr;
+  bf16* Kw = nullptr; bf16* VTw = nullptr;  // the caches again, writable
 };
 
 
@@ -747,13 +753,79 @@ __global__ __launch_bounds__(64 * WAVES, DEC_HD == 256 ? 1 : (WAVES == 8 ? 2 : 3
   const bf16* Vp = a.VT + b * a.v_seq + hk * a.v_head;
 
   bf16x8 qf[KS];
+  if (a.slabs) {
+    // ---- what decode_qkv_finish_kernel did in a launch of its own, for this (read, kv head): sum the split-K slabs of the
+    // QKV projection (+ bias) of the G query heads, the key and the value head, round to bf16, rotate q and k at position
+    // lens - 1 + rope_delta (the reference's bf16 rounding chain), append k / v to the cache at slot lens - 1 — then the
+    // attention below reads the slot back like any other.  Scratch lives in s_o, which the loop does not touch.
+    constexpr int HALF = DEC_HD / 2;
+    bf16* s_row = (bf16*)&s_o[0][0][0];         // [G + 2][DEC_HD]: q heads, k, v as bf16(sum + bias)
+    bf16* s_rot = s_row + 18 * DEC_HD;          // [G][DEC_HD]: rotated q heads
+    const int slot = len - 1, pos = slot + a.rope_delta[b];
+    if (slot < 0 || slot >= a.ctx || pos < 0 || pos >= a.max_pos) {  // uniform over every workgroup of this read
+      // the host's invariants are broken (hwocr.h, HWOCR_STATUS_BAD_POSITION): nothing of this read is written
+      if (tid == 0 && a.status) atomicOr(a.status, HWOCR_STATUS_BAD_POSITION);
+      return;
+    }
+    // the workgroup whose key blocks include the new slot appends it (the only one that reads it back)
+    const bool owner = split == ((slot >> 5) % (a.nsplit * WAVES)) / WAVES;
+    const int W = (a.Hq + 2 * a.Hkv) * DEC_HD;
+    for (int i4 = tid; i4 < (a.G + 2) * (DEC_HD / 4); i4 += 64 * WAVES) {
+      const int which = i4 / (DEC_HD / 4), d = 4 * (i4 % (DEC_HD / 4));
+      const int col = (which < a.G ? hk * a.G + which : which == a.G ? a.Hq + hk : a.Hq + a.Hkv + hk) * DEC_HD + d;
+      f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int sl = 0; sl < a.nslab; ++sl) y += *(const f32x4*)(a.slabs + sl * a.slab_stride + (long)b * W + col);
+      if (a.bias) {
+        const bf16x4 bb = *(const bf16x4*)(a.bias + col);
 #pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    if (c < a.G)
-      qf[s] = *(const bf16x8*)(a.Q + ((long)b * a.Hq + hk * a.G + c) * DEC_HD + 32 * s + 8 * qd);
-    else
+        for (int e = 0; e < 4; ++e) y[e] += bf2f(bb[e]);
+      }
+      bf16x4 o4;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)0.0f;
+      for (int e = 0; e < 4; ++e) o4[e] = f2bf(y[e]);
+      *(bf16x4*)(s_row + which * DEC_HD + d) = o4;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < (a.G + 1) * HALF; idx += 64 * WAVES) {
+      const int which = idx / HALF, i = idx % HALF;
+      if (which == a.G && !owner) continue;
+      const float cs = bf2f(a.cos_tab[(long)pos * HALF + i]), sn = bf2f(a.sin_tab[(long)pos * HALF + i]);
+      const float x1 = bf2f(s_row[which * DEC_HD + i]), x2 = bf2f(s_row[which * DEC_HD + HALF + i]);
+      const bf16 oa = f2bf(rbf(x1 * cs) + rbf(-x2 * sn));
+      const bf16 ob = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
+      if (which < a.G) {
+        s_rot[which * DEC_HD + i] = oa;
+        s_rot[which * DEC_HD + HALF + i] = ob;
+      } else {
+        bf16* kb = a.Kw + b * a.k_seq + hk * a.k_head;
+        kb[TILED ? kv_tiled_k(slot, i) : (long)slot * DEC_HD + i] = oa;
+        kb[TILED ? kv_tiled_k(slot, HALF + i) : (long)slot * DEC_HD + HALF + i] = ob;
+      }
+    }
+    if (owner) {
+      for (int d = tid; d < DEC_HD; d += 64 * WAVES)
+        a.VTw[b * a.v_seq + hk * a.v_head + (TILED ? kv_tiled_v(d, slot) : (long)d * a.v_row + slot)] = s_row[(a.G + 1) * DEC_HD + d];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the appended slot is in L2 before any wave reads it back
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (c < a.G)
+        qf[s] = *(const bf16x8*)(s_rot + c * DEC_HD + 32 * s + 8 * qd);
+      else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)0.0f;
+    }
+    __syncthreads();  // s_o is the merge buffer again
+  } else {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (c < a.G)
+        qf[s] = *(const bf16x8*)(a.Q + ((long)b * a.Hq + hk * a.G + c) * DEC_HD + 32 * s + 8 * qd);
+      else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)0.0f;
+    }
   }
 
   f32x4 o[VD];
@@ -945,34 +1017,65 @@ extern "C" int hwocr_attn_varlen(const void* Q, const void* K, const void* VT, v
   return HWOCR_EINVAL;
 }
 
-extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out,
-                                 float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit,
-                                 long k_seq, long k_head, long v_seq, long v_head, long v_row, float scale,
-                                 int head_dim, int kv_tiled, hipStream_t stream) {
-  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
-  // nsplit <= 16: the partial buffers of hwocr_dec_ws are sized for 16 splits (engine._dec_ws)
-  if (nseq <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16 || nsplit < 1 || nsplit > 16) return HWOCR_EINVAL;
-  if (nsplit > 1 && (!part_o || !part_ml)) return HWOCR_EINVAL;
-  if ((v_row % 64) || (k_seq % 8) || (k_head % 8) || (v_seq % 8) || (v_head % 8)) return HWOCR_EINVAL;
-  if ((head_dim != 128 && head_dim != 256) || (kv_tiled && head_dim != 128)) return HWOCR_EINVAL;
-  if (head_dim == 256 && Hq / Hkv > 8) return HWOCR_EINVAL;
-  DecodeArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, lens, part_o, part_ml, (bf16*)out,
-               k_seq, k_head, v_seq, v_head, v_row, Hq, Hkv, Hq / Hkv, nsplit, scale * 1.4426950408889634f, kv_tiled};
+namespace {
+int launch_attn_decode(const DecodeArgs& a, int nseq, int head_dim, hipStream_t stream) {
+  const int Hkv = a.Hkv, nsplit = a.nsplit;
   if (head_dim == 256) {  // 4 waves; a single pass when the caller asks for no split
     hipLaunchKernelGGL((attn_decode_kernel<false, 4, 256>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
     if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<256>, dim3(Hkv, nseq), dim3(256), 0, stream, a);
     return hwocr_launch_status();
   }
   if (nsplit == 1) {
-    if (kv_tiled) hipLaunchKernelGGL((attn_decode_kernel<true, 8, 128>), dim3(1, Hkv, nseq), dim3(512), 0, stream, a);
+    if (a.kv_tiled) hipLaunchKernelGGL((attn_decode_kernel<true, 8, 128>), dim3(1, Hkv, nseq), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((attn_decode_kernel<false, 8, 128>), dim3(1, Hkv, nseq), dim3(512), 0, stream, a);
-  } else if (kv_tiled) {
+  } else if (a.kv_tiled) {
     hipLaunchKernelGGL((attn_decode_kernel<true, 4, 128>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
   } else {
     hipLaunchKernelGGL((attn_decode_kernel<false, 4, 128>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
   }
   if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<128>, dim3(Hkv, nseq), dim3(256), 0, stream, a);
   return hwocr_launch_status();
+}
+bool attn_decode_args_ok(int nseq, int Hq, int Hkv, int nsplit, float* part_o, float* part_ml, long k_seq, long k_head,
+                         long v_seq, long v_head, long v_row, int head_dim, int kv_tiled) {
+  // nsplit <= 16: the partial buffers of hwocr_dec_ws are sized for 16 splits (engine._dec_ws)
+  if (nseq <= 0 || Hq <= 0 || Hkv <= 0 || (Hq % Hkv) || Hq / Hkv > 16 || nsplit < 1 || nsplit > 16) return false;
+  if (nsplit > 1 && (!part_o || !part_ml)) return false;
+  if ((v_row % 64) || (k_seq % 8) || (k_head % 8) || (v_seq % 8) || (v_head % 8)) return false;
+  if ((head_dim != 128 && head_dim != 256) || (kv_tiled && head_dim != 128)) return false;
+  if (head_dim == 256 && Hq / Hkv > 8) return false;
+  return true;
+}
+}  // namespace
+
+extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out,
+                                 float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit,
+                                 long k_seq, long k_head, long v_seq, long v_head, long v_row, float scale,
+                                 int head_dim, int kv_tiled, hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
+  if (!attn_decode_args_ok(nseq, Hq, Hkv, nsplit, part_o, part_ml, k_seq, k_head, v_seq, v_head, v_row, head_dim, kv_tiled))
+    return HWOCR_EINVAL;
+  DecodeArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, lens, part_o, part_ml, (bf16*)out,
+               k_seq, k_head, v_seq, v_head, v_row, Hq, Hkv, Hq / Hkv, nsplit, scale * 1.4426950408889634f, kv_tiled};
+  return launch_attn_decode(a, nseq, head_dim, stream);
+}
+
+// hwocr_decode_qkv_finish + hwocr_attn_decode in one launch (hwocr.h)
+extern "C" int hwocr_attn_decode_qkv(const float* slabs, int nslab, long slab_stride, const void* bias, void* K, void* VT,
+                                     const int* lens, const int* rope_delta, const void* cos_tab, const void* sin_tab, void* out,
+                                     float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq,
+                                     long k_head, long v_seq, long v_head, long v_row, float scale, int head_dim, int kv_tiled,
+                                     int ctx, int max_pos, int* status, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!attn_decode_args_ok(nseq, Hq, Hkv, nsplit, part_o, part_ml, k_seq, k_head, v_seq, v_head, v_row, head_dim, kv_tiled))
+    return HWOCR_EINVAL;
+  if (!slabs || nslab < 1 || !rope_delta || !cos_tab || !sin_tab || ctx < 1 || max_pos < 1 || !K || !VT) return HWOCR_EINVAL;
+  DecodeArgs a{nullptr, (const bf16*)K, (const bf16*)VT, lens, part_o, part_ml, (bf16*)out,
+               k_seq, k_head, v_seq, v_head, v_row, Hq, Hkv, Hq / Hkv, nsplit, scale * 1.4426950408889634f, kv_tiled};
+  a.slabs = slabs; a.nslab = nslab; a.slab_stride = slab_stride; a.bias = (const bf16*)bias; a.rope_delta = rope_delta;
+  a.cos_tab = (const bf16*)cos_tab; a.sin_tab = (const bf16*)sin_tab; a.ctx = ctx; a.max_pos = max_pos; a.status = status;
+  a.Kw = (bf16*)K; a.VTw = (bf16*)VT;
+  return launch_attn_decode(a, nseq, head_dim, stream);
 }
 
 // the kernel instance hwocr_attn_decode runs for these arguments (for the parity tests' coverage check)

@@ -275,11 +275,19 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
     bf16* Vc = B(kv->vt) + l * k_layer;
     CHECK(hwocr_gemm_skinny(ws->hn, L.qkv_wt ? L.qkv_wt : L.qkv_w, nullptr, ws->slabs, nseq, QW, Hd, Hd, Hd, QW,
                             HWOCR_EPI_PARTIAL, s_qkv, L.qkv_wt != nullptr, st));
-    CHECK(hwocr_decode_qkv_finish(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, ws->q, Kc, Vc, gs->lens, gs->rope_delta,
-                                  m->rope_cos, m->rope_sin, nseq, m->Hq, m->Hkv, k_seq, k_head, k_seq, k_head,
-                                  kv->ctx, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
-    CHECK(hwocr_attn_decode(ws->q, Kc, Vc, gs->lens, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv,
-                            attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, HD, kv->tiled, st));
+    // bias + rotary + cache append of this step's q / k / v ride in the attention launch (one launch per layer less;
+    // HWOCR_DECODE_FUSE_QKV=0: the two separate launches, for A/B runs)
+    static const bool fuse_qkv = [] { const char* e = getenv("HWOCR_DECODE_FUSE_QKV"); return !e || atoi(e) != 0; }();
+    if (!fuse_qkv) {
+      CHECK(hwocr_decode_qkv_finish(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, ws->q, Kc, Vc, gs->lens, gs->rope_delta,
+                                    m->rope_cos, m->rope_sin, nseq, m->Hq, m->Hkv, k_seq, k_head, k_seq, k_head,
+                                    kv->ctx, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
+      CHECK(hwocr_attn_decode(ws->q, Kc, Vc, gs->lens, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv,
+                              attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, HD, kv->tiled, st));
+    } else
+    CHECK(hwocr_attn_decode_qkv(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, Kc, Vc, gs->lens, gs->rope_delta, m->rope_cos,
+                                m->rope_sin, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv, attn_splits, k_seq, k_head,
+                                k_seq, k_head, kv->ctx, scale, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
     CHECK(hwocr_gemm_skinny(ws->attn, L.o_wt ? L.o_wt : L.o_w, nullptr, ws->slabs, nseq, Hd, OW, OW, OW, Hd,
                             HWOCR_EPI_PARTIAL, s_o, L.o_wt != nullptr, st));
     CHECK(hwocr_add_rmsnorm(ws->slabs, s_o, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd,

@@ -103,6 +103,16 @@ int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* l
                       float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head, long v_seq,
                       long v_head, long v_row, float scale, int head_dim, int kv_tiled, hwocr_stream_t stream);
 
+/* hwocr_decode_qkv_finish (below) and hwocr_attn_decode in ONE launch: every (read, kv head) workgroup first sums the slabs of
+ * its query heads, its key and its value head, rotates, appends k / v at cache slot lens - 1, then attends over lens keys.
+ * Same arithmetic in the same order: outputs and cache bit-identical to the two calls.  The Q buffer is not used.  Reads outside
+ * the invariants of hwocr_decode_qkv_finish are skipped as there (no output, HWOCR_STATUS_BAD_POSITION raised in *status). */
+int hwocr_attn_decode_qkv(const float* slabs, int nslab, long slab_stride, const void* bias, void* K, void* VT,
+                          const int* lens, const int* rope_delta, const void* cos_tab, const void* sin_tab, void* out,
+                          float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head,
+                          long v_seq, long v_head, long v_row, float scale, int head_dim, int kv_tiled, int ctx, int max_pos,
+                          int* status, hwocr_stream_t stream);
+
 /* as hwocr_gemm_skinny_variant, for hwocr_attn_decode */
 int hwocr_attn_decode_variant(int nsplit, int head_dim, int kv_tiled, char* name, int name_len);
 

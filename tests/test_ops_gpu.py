@@ -731,6 +731,85 @@ def test_decode_qkv_finish_flags_reads_outside_their_invariants(tiled):
     assert all(bool(Q[b].float().abs().sum() != 0) != bad[b] for b in range(B))
 
 
+@pytest.mark.parametrize("hd,Hq,Hkv,tiled,nsplit,B", [(128, 12, 2, 1, 1, 9), (128, 12, 2, 1, 4, 5), (128, 28, 4, 0, 1, 6),
+                                                      (128, 6, 2, 0, 3, 4), (256, 8, 1, 0, 1, 5), (256, 8, 1, 0, 4, 5),
+                                                      (128, 12, 2, 1, 1, 252)])
+def test_attn_decode_qkv_equals_finish_then_attention(hd, Hq, Hkv, tiled, nsplit, B):
+    """hwocr_attn_decode_qkv (slab sum + bias + rotary + cache append inside the attention launch) against the two launches
+    it replaces: same attention output, same cache, bit for bit — including reads whose new slot opens a fresh 32-key block and
+    reads at the first and the last cache position."""
+    ctx, nslab, max_pos = 512, 3, 1024
+    W = (Hq + 2 * Hkv) * hd
+    g = torch.Generator().manual_seed(9)
+    lens = torch.randint(2, ctx, (B,), generator=g).tolist()
+    lens[0], lens[1], lens[2], lens[3] = 1, ctx, 33, 64            # first slot, last slot, first of a block, last of a block
+    delta = torch.randint(-1, 300, (B,), generator=g).tolist()
+    delta[0] = 0
+    slabs = torch.randn(nslab, B, W, device=DEV)
+    bias = randbf(W, seed=30) if hd == 128 else None               # Gemma projections carry no bias
+    cos_t, sin_t = _rope_tables(max_pos, hd=hd)
+    k = randbf(B, Hkv, ctx, hd, seed=16)
+    v = randbf(B, Hkv, ctx, hd, seed=17)
+    vt = v.transpose(2, 3).contiguous()
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    delta_d = torch.tensor(delta, dtype=torch.int32, device=DEV)
+    cos_d, sin_d = cos_t.to(DEV), sin_t.to(DEV)
+    G = Hq // Hkv
+    strides = (Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx)
+
+    def caches():
+        return (tile_k(k), tile_v(vt)) if tiled else (k.clone(), vt.clone())
+
+    def parts():
+        return (torch.zeros(B * Hkv * nsplit * G * hd, dtype=torch.float32, device=DEV),
+                torch.zeros(B * Hkv * nsplit * G * 2, dtype=torch.float32, device=DEV))
+
+    # two launches
+    K0, V0 = caches()
+    Q0 = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    st0 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    po, pm = parts()
+    out0 = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    assert lib().hwocr_decode_qkv_finish(p(slabs), nslab, B * W, p(bias), p(Q0), p(K0), p(V0), p(lens_d), p(delta_d), p(cos_d),
+                                         p(sin_d), B, Hq, Hkv, *strides, hd, tiled, ctx, max_pos, p(st0), st()) == 0
+    assert lib().hwocr_attn_decode(p(Q0), p(K0), p(V0), p(lens_d), p(out0), p(po), p(pm), B, Hq, Hkv, nsplit, *strides,
+                                   hd ** -0.5, hd, tiled, st()) == 0
+    # one launch
+    K1, V1 = caches()
+    st1 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    po1, pm1 = parts()
+    out1 = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    assert lib().hwocr_attn_decode_qkv(p(slabs), nslab, B * W, p(bias), p(K1), p(V1), p(lens_d), p(delta_d), p(cos_d), p(sin_d),
+                                       p(out1), p(po1), p(pm1), B, Hq, Hkv, nsplit, *strides, hd ** -0.5, hd, tiled, ctx, max_pos,
+                                       p(st1), st()) == 0
+    sync()
+    assert int(st0) == 0 and int(st1) == 0
+    assert torch.equal(K1, K0) and torch.equal(V1, V0), "cache after the fused launch differs"
+    assert torch.equal(out1, out0), "attention output of the fused launch differs"
+    assert bool(torch.isfinite(out1.float()).all())
+
+
+def test_attn_decode_qkv_flags_reads_outside_their_invariants():
+    hd, Hq, Hkv, B, ctx, nslab, max_pos = 128, 4, 2, 4, 128, 2, 160
+    W = (Hq + 2 * Hkv) * hd
+    slabs = torch.randn(nslab, B, W, device=DEV)
+    lens = torch.tensor([10, 1, 129, 100], dtype=torch.int32, device=DEV)       # ok, stale negative delta, slot past ctx, pos past table
+    delta = torch.tensor([-3, -1295, 0, 80], dtype=torch.int32, device=DEV)
+    cos_t, sin_t = _rope_tables(max_pos, hd=hd)
+    Kc = torch.zeros(B, Hkv, ctx, hd, dtype=torch.bfloat16, device=DEV)
+    VT = torch.zeros(B, Hkv, hd, ctx, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    cos_d, sin_d = cos_t.to(DEV), sin_t.to(DEV)
+    assert lib().hwocr_attn_decode_qkv(p(slabs), nslab, B * W, None, p(Kc), p(VT), p(lens), p(delta), p(cos_d), p(sin_d), p(out),
+                                       None, None, B, Hq, Hkv, 1, Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx,
+                                       hd ** -0.5, hd, 0, ctx, max_pos, p(status), st()) == 0
+    sync()
+    assert int(status) == 1
+    touched = [bool(Kc[b].float().abs().sum() != 0) or bool(out[b].float().abs().sum() != 0) for b in range(B)]
+    assert touched == [True, False, False, False]
+
+
 def test_embed_splice():
     V, D, rows = 100, 256, 20
     table = randbf(V, D, seed=31)
