@@ -379,7 +379,7 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the read engine has no CPU path)")
     rank, local, world = shard.init_from_env()
-    dev = torch.device(f"cuda:{local}")
+    dev = torch.device(f"cuda:{shard.local_device_index(local)}")
     torch.cuda.set_device(dev)
     import torch.distributed as dist
 

@@ -41,7 +41,7 @@ def hipcc_path() -> str:
 
 def build_hip(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "gemm_common.cuh"), os.path.join(CSRC, "common.cuh"), os.path.join(INCLUDE, "hwocr.h")]
+    deps = srcs + [os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "hwocr.h")]
     if not force and _newer(HIP_LIB, deps):
         return HIP_LIB
     objs = []

@@ -11,7 +11,7 @@
 //  attn_decode  : one new token per read against its KV cache (HBM-bound).  K rows and V^T rows go
 //                 straight from HBM to MFMA operands; keys are split over waves and workgroups and merged
 //                 with the usual (m, l, O) rule.
-#include "common.cuh"
+#include "common.h"
 #include "hwocr.h"
 #include <cstdio>
 #include <cstdlib>
@@ -28,7 +28,7 @@ struct PrefillArgs {
   long o_seg, o_row;
   int group;          // query heads per kv head
   float scale_log2;   // softmax scale * log2(e)
-  int kv_tiled;       // K / V^T in the fragment-tiled cache layout (common.cuh) instead of rows
+  int kv_tiled;       // K / V^T in the fragment-tiled cache layout (common.h) instead of rows
   int heads, nseg, qblocks;  // 1-D grid decomposition (attn_vit80_kernel)
   const int* seg_off;        // packed ragged segments (hwocr_attn_varlen): first row of every segment, multiple of 4
   // Lazy running-max update of the two specialised kernels: the accumulators are rescaled only when some query's tile maximum

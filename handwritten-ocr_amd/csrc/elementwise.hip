@@ -2,7 +2,7 @@
 // vector accesses, one wave per row for the norms, LDS tiles wherever a transpose is needed.
 // Every kernel cites the reference-side operation it replaces (HF = transformers, the library the
 // reference's run_ocr calls at ocr_agent/tools.py:756-769).
-#include "common.cuh"
+#include "common.h"
 #include "hwocr.h"
 
 namespace {

@@ -16,7 +16,7 @@
 //
 // Epilogues reproduce the points where the reference's bf16 modules materialise a tensor
 // (HF modeling_qwen2_vl.py:293-301 VisionMlp, :453-466 Qwen2MLP, :442-448 residual adds).
-#include "gemm_common.cuh"
+#include "gemm_common.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

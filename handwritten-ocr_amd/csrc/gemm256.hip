@@ -28,7 +28,7 @@
 // lane's 32-byte operand = the two 16-byte chunks the bf16 form feeds to its two k-steps.  The k order inside the
 // instruction is therefore permuted, identically for both operands, which a dot product does not see.  Operands carry
 // one fp32 scale per row (activation) / per output feature (weight); the epilogue multiplies them in before the bias.
-#include "gemm_common.cuh"
+#include "gemm_common.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
   const int ntiles = a.tilesM * a.tilesN;
   int tile = blockIdx.x;
   int m0, n0;
-  auto origin_of = [&](int id) {  // XCD-contiguous chunks, then 4 row panels swept column-major (gemm_common.cuh)
+  auto origin_of = [&](int id) {  // XCD-contiguous chunks, then 4 row panels swept column-major (gemm_common.h)
     int tm, tn;
     tile_of_id(id, a.tilesM, a.tilesN, 4, tm, tn);
     m0 = tm * BM;

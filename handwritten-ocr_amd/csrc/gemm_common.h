@@ -1,7 +1,7 @@
 // Shared by the GEMM kernels: epilogue codes, activation helpers with the reference's bf16 rounding points, the
 // argument block of the wide kernels and the per-tile epilogue store.
 #pragma once
-#include "common.cuh"
+#include "common.h"
 #include "hwocr.h"
 
 namespace gemm {

@@ -35,7 +35,7 @@
 // GEMM (MI355X_MICROARCH.md, rows ring-gemm / ring-vs-splitk: 25 MB of weights x 192 rows in 14.7-19.7 us = 1.3-1.7 TB/s of
 // weights) is slower per weight byte than this kernel (55 MB x 252 rows in 26.5 us = 2.1 TB/s).
 // Epilogues as gemm_skinny: PARTIAL fp32 split-K slabs, LINEAR (+bias), SWIGLU / GEGLU on interleaved gate/up tile pairs.
-#include "gemm_common.cuh"
+#include "gemm_common.h"
 #include <cstdlib>
 
 using namespace gemm;

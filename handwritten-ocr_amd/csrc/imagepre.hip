@@ -10,7 +10,7 @@
 //                  (HF image_processing_pil_qwen2_vl.py:152-183 -> libImaging/Resample.c); coefficient tables come from the host
 //                  (handwritten-ocr_amd/gpupre.py restates precompute_coeffs)
 // Images are uint8 [H][W][3].  These are byte-granular HBM-bound kernels: one pass each, 4 bytes per lane.
-#include "common.cuh"
+#include "common.h"
 #include "hwocr.h"
 
 namespace {

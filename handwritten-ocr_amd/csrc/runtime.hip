@@ -6,7 +6,7 @@
 //   hwocr_decode_step  <- one iteration of GenerationMixin._sample's while loop (HF generation/utils.py:2876-2941)
 // The decode step touches only device state (token ids, lengths, stop flags live in HBM), so it can be captured
 // once into a HIP graph and replayed for every generated token without a host round trip.
-#include "common.cuh"
+#include "common.h"
 #include "hwocr.h"
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +21,7 @@
 namespace {
 inline bf16* B(void* p) { return (bf16*)p; }
 inline const bf16* B(const void* p) { return (const bf16*)p; }
-inline bool hwocr_vit_qkv_fusable(int M, int heads, int hd) {  // == gemm::vit_qkv_fusable (gemm_common.cuh)
+inline bool hwocr_vit_qkv_fusable(int M, int heads, int hd) {  // == gemm::vit_qkv_fusable (gemm_common.h)
   return M >= 1024 && (heads * hd) % 256 == 0 && hd % 16 == 0 && hd <= 128;
 }
 inline int pick_splitk(int K, int N, int want_wgs) {

@@ -131,7 +131,7 @@ def preset(name: str) -> ModelConfig:
     if name in ("qwen2.5-vl-3b", "Qwen/Qwen2.5-VL-3B-Instruct"):
         return ModelConfig(name="qwen2.5-vl-3b", family="qwen2_5_vl", vit_inter=3420, hidden=2048, layers=36, q_heads=16,
                            kv_heads=2, inter=11008, vocab=151936, tie=True)
-    if name in ("paligemma-3b", "google/paligemma-3b-mix-896"):  # BASELINE config 4 (bf16; fp8 GEMMs are not built)
+    if name in ("paligemma-3b", "google/paligemma-3b-mix-896"):  # BASELINE config 4 (bf16; ReadEngine(fp8=True): E4M3 wide GEMMs)
         return ModelConfig(name="paligemma-3b", family="paligemma", depth=27, embed_dim=1152, num_heads=16, vit_inter=4304,
                            merge=1, tps=1, image_size=896, head_dim=256, hidden=2048, layers=18, q_heads=8, kv_heads=1,
                            inter=16384, vocab=257216, rope_theta=10000.0, tie=True, image_token_id=257152, eos_ids=(1,),
@@ -881,6 +881,7 @@ class ReadEngine:
         ws = self._dec_ws(max(pb * Tp, self.max_reads))
         step_logits = [] if return_logits else None
         first_logits = []
+        chunk_keep = []
         for s0 in range(0, R, pb):
             n = min(pb, R - s0)
             last = torch.tensor([j * Tp + T[s0 + j] - 1 for j in range(n)], dtype=torch.int32, device=dev)
@@ -891,7 +892,7 @@ class ReadEngine:
                                          max(T[s0: s0 + n]), st), "hwocr_prefill")
             if return_logits:
                 first_logits.append(self._bufs["logits"][:n].clone())
-            torch.cuda.current_stream().synchronize()  # the chunk's index tensors die with this iteration
+            chunk_keep.append((last, pos_chunk))  # index tensors stay alive until the stream has consumed them (no host sync per chunk)
         mark("prefill")
         if return_logits:
             step_logits.append(torch.cat(first_logits, dim=0))
@@ -995,6 +996,8 @@ class ReadEngine:
         splits = self.attn_splits or pick_attn_splits(R, c.kv_heads)
         ws = self._dec_ws(max(min(self.prefill_batch, R) * _ceil(Tmax, 64), self.max_reads))
 
+        admit_keep: list = []  # device tensors the queued prefill launches read; released after the next synchronisation
+
         def admit(slots: list[int]) -> None:
             nonlocal nxt
             reads = list(range(nxt, nxt + len(slots)))
@@ -1021,6 +1024,7 @@ class ReadEngine:
             d_ids, d_img = torch.from_numpy(ids).to(dev), torch.from_numpy(img_row).to(dev)
             d_pos, d_seq = torch.from_numpy(pos3).to(dev), torch.tensor(T, dtype=torch.int32, device=dev)
             sl = torch.tensor(slots, dtype=torch.long, device=dev)
+            admit_keep.append((d_ids, d_img, d_pos, d_seq, emb))  # alive until the next host sync of the decode loop
             self.lens[sl] = d_seq
             self.rope_delta[sl] = torch.from_numpy(delta).to(dev)
             self.n_gen[sl] = 0
@@ -1045,7 +1049,7 @@ class ReadEngine:
                                              _lib.ptr(d_ids[j0:j1]), _lib.ptr(d_img[j0:j1]), _lib.ptr(emb), _lib.ptr(pos_chunk),
                                              _lib.ptr(d_seq[j0:j1]), _lib.ptr(last), k, Tp, slots[j0], max(T[j0:j1]), st),
                            "hwocr_prefill")
-                torch.cuda.current_stream().synchronize()
+                admit_keep.append((last, pos_chunk))
                 j0 = j1
             for s, r in zip(slots, reads):
                 slot_read[s] = r
@@ -1069,6 +1073,7 @@ class ReadEngine:
             else:
                 _lib.check(lib.hwocr_decode_graph_launch(self._use_graph(key), sync_every, st), "hwocr_decode_graph_launch")
             torch.cuda.current_stream().synchronize()
+            admit_keep.clear()
             self._check_status()
             fin = self.finished[:R].cpu().numpy()
             ng = self.n_gen[:R].cpu().numpy()

@@ -14,8 +14,20 @@ import torch
 import torch.distributed as dist
 
 
+def local_device_index(local_rank: int) -> int:
+    """CUDA device of a rank: its LOCAL_RANK.  More ranks than GPUs is an error — unless HWOCR_ALLOW_SHARED_GPU=1 says the
+    ranks may share devices (a rehearsal of the multi-rank path on a one-GPU box; then the collective runs over gloo)."""
+    n = torch.cuda.device_count()
+    if n and local_rank >= n:
+        if os.environ.get("HWOCR_ALLOW_SHARED_GPU", "0") in ("", "0"):
+            raise RuntimeError(f"LOCAL_RANK {local_rank} but only {n} GPU(s) are visible: one process per GPU")
+        return local_rank % n
+    return local_rank
+
+
 def init_from_env(device_backend: bool = True) -> tuple[int, int, int]:
-    """(rank, local_rank, world).  Initialises torch.distributed when WORLD_SIZE > 1."""
+    """(rank, local_rank, world).  Initialises torch.distributed when WORLD_SIZE > 1: "nccl" (= RCCL on ROCm, over xGMI)
+    when the ranks own their GPUs, "gloo" on CPU and when ranks share a GPU (RCCL refuses two ranks on one device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -24,7 +36,9 @@ def init_from_env(device_backend: bool = True) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29511")
         use_nccl = device_backend and torch.cuda.is_available()
         if use_nccl:
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local_device_index(local))
+            if local >= torch.cuda.device_count():
+                use_nccl = False
         dist.init_process_group(backend="nccl" if use_nccl else "gloo", rank=rank, world_size=world)
     return rank, local, world
 

@@ -39,8 +39,10 @@ def _device() -> str:
     """One process per GPU: the rank's own device (LOCAL_RANK, set by torchrun / bench.py), else the current one."""
     import torch
 
+    from . import shard
+
     local = os.environ.get("LOCAL_RANK")
-    return f"cuda:{int(local)}" if local is not None else f"cuda:{torch.cuda.current_device()}"
+    return f"cuda:{shard.local_device_index(int(local))}" if local is not None else f"cuda:{torch.cuda.current_device()}"
 
 
 def _load_ocr_model():

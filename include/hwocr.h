@@ -257,7 +257,7 @@ typedef struct {
 } hwocr_decoder;
 
 typedef struct { /* KV cache: K [layer][seq][Hkv][ctx][128], VT [layer][seq][Hkv][128][ctx]; tiled != 0: every
-                  * (seq, kv head) region is stored in the fragment-tiled order of csrc/common.cuh (kv_tiled_k/_v) */
+                  * (seq, kv head) region is stored in the fragment-tiled order of csrc/common.h (kv_tiled_k/_v) */
   void* k; void* vt; int nseq_max, ctx, tiled;
 } hwocr_kv;
 

@@ -61,7 +61,7 @@ def _v_offsets(ctx):
 
 
 def tile_k(k):
-    """[..., ctx, 128] row-major -> the fragment-tiled cache order (csrc/common.cuh kv_tiled_k), same shape."""
+    """[..., ctx, 128] row-major -> the fragment-tiled cache order (csrc/common.h kv_tiled_k), same shape."""
     ctx = k.shape[-2]
     out = torch.empty_like(k).view(*k.shape[:-2], ctx * 128)
     out[..., _k_offsets(ctx).to(k.device)] = k.reshape(*k.shape[:-2], ctx * 128)
