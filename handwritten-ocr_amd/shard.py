@@ -37,7 +37,8 @@ def init_from_env(device_backend: bool = True) -> tuple[int, int, int]:
         use_nccl = device_backend and torch.cuda.is_available()
         if use_nccl:
             torch.cuda.set_device(local_device_index(local))
-            if local >= torch.cuda.device_count():
+            # ranks sharing a GPU (rehearsal, HWOCR_ALLOW_SHARED_GPU=1): EVERY rank must take gloo, not only the surplus ones
+            if int(os.environ.get("LOCAL_WORLD_SIZE", world)) > torch.cuda.device_count():
                 use_nccl = False
         dist.init_process_group(backend="nccl" if use_nccl else "gloo", rank=rank, world_size=world)
     return rank, local, world
