@@ -442,6 +442,30 @@ extern "C" int hwocr_gemm_wide_fp8(const void* X8, const float* xscale, const vo
   return rc;
 }
 
+// QKV projection of a vision block with rotary + head split + V transpose in the epilogue (hwocr.h); timed with the other wide
+// GEMMs when the bench's profile is on
+extern "C" int hwocr_gemm_vit_qkv(const void* X, const void* W, const void* bias, int M, int K, int ldx, int ldw,
+                                  const float* xscale, const float* wscale, const hwocr_vit_split* sp, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!X || !W || !sp || !sp->Q || !sp->K || !sp->VT || !sp->pos_h || !sp->pos_w || !sp->cos_tab || !sp->sin_tab) return HWOCR_EINVAL;
+  const bool fp8 = xscale != nullptr || wscale != nullptr;
+  if (fp8 && (!xscale || !wscale)) return HWOCR_EINVAL;
+  if (M <= 0 || K <= 0 || sp->heads <= 0 || !vit_qkv_fusable(M, sp->heads, sp->hd) || sp->tok_ld < M || (sp->tok_ld % 64)) return HWOCR_EINVAL;
+  if (fp8 ? ((K % 128) || (ldx % 16) || (ldw % 16)) : ((K % BK) || (ldx % 8) || (ldw % 8))) return HWOCR_EINVAL;
+  const int N = 3 * sp->heads * sp->hd;
+  WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, nullptr, nullptr, M, N, K, ldx, ldw, 0, 0, 0, 0, xscale, wscale, *sp};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const bool prof = g_prof.on == (fp8 ? 2 : 1) && g_prof.slot(ev0, ev1);
+  if (prof) (void)hipEventRecord(ev0, stream);
+  const int rc = hwocr_gemm_wide256_vit_qkv(a, fp8, stream);
+  if (prof) {
+    (void)hipEventRecord(ev1, stream);
+    g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
+    ++g_prof.n;
+  }
+  return rc;
+}
+
 // [N][K] row-major -> fragment-tiled copy for gemm_skinny (layout in the kernel comment).  16-byte granules.
 __global__ __launch_bounds__(256) void tile_weights_kernel(const bf16* src, bf16* dst, int N, int K, int ldw) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;  // one 16-byte granule each

@@ -612,16 +612,7 @@ int hwocr_gemm_wide256_fp8(const WideArgs& a, int epi, hipStream_t stream) {
   return dispatch<true>(a, epi, stream);
 }
 
-// QKV projection of a vision block with rotary + head split + V transpose in the epilogue (hwocr.h)
-extern "C" int hwocr_gemm_vit_qkv(const void* X, const void* W, const void* bias, int M, int K, int ldx, int ldw,
-                                  const float* xscale, const float* wscale, const hwocr_vit_split* sp, hipStream_t stream) {
-  (void)hipGetLastError();
-  if (!X || !W || !sp || !sp->Q || !sp->K || !sp->VT || !sp->pos_h || !sp->pos_w || !sp->cos_tab || !sp->sin_tab) return HWOCR_EINVAL;
-  const bool fp8 = xscale != nullptr || wscale != nullptr;
-  if (fp8 && (!xscale || !wscale)) return HWOCR_EINVAL;
-  if (M <= 0 || K <= 0 || sp->heads <= 0 || !vit_qkv_fusable(M, sp->heads, sp->hd) || sp->tok_ld < M || (sp->tok_ld % 64)) return HWOCR_EINVAL;
-  if (fp8 ? ((K % 128) || (ldx % 16) || (ldw % 16)) : ((K % BK) || (ldx % 8) || (ldw % 8))) return HWOCR_EINVAL;
-  WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, nullptr, nullptr, M, 3 * sp->heads * sp->hd, K, ldx, ldw, 0, 0, 0, 0,
-             xscale, wscale, *sp};
+// QKV projection of a vision block with rotary + head split + V transpose in the epilogue (entry point: gemm.hip)
+int hwocr_gemm_wide256_vit_qkv(const WideArgs& a, bool fp8, hipStream_t stream) {
   return fp8 ? dispatch<true>(a, EPI_VIT_QKV, stream) : dispatch<false>(a, EPI_VIT_QKV, stream);
 }

@@ -135,4 +135,5 @@ inline bool vit_qkv_fusable(int M, int heads, int hd) {
 // launcher of the 256x256 kernel (gemm256.hip); returns HWOCR_EINVAL when the shape does not qualify
 int hwocr_gemm_wide256(const gemm::WideArgs& a, int epi, hipStream_t stream);
 int hwocr_gemm_wide256_fp8(const gemm::WideArgs& a, int epi, hipStream_t stream);
+int hwocr_gemm_wide256_vit_qkv(const gemm::WideArgs& a, bool fp8, hipStream_t stream);
 
