@@ -80,13 +80,13 @@ class VitWs(C.Structure):
 class DecLayer(C.Structure):
     _fields_ = [(n, P) for n in ("in_norm_w", "qkv_w", "qkv_b", "o_w", "post_norm_w", "gate_up_w", "down_w",
                                   "qkv_wt", "o_wt", "gate_up_wt", "down_wt")] + [
-        (n, W8) for n in ("qkv8", "o8", "gate_up8", "down8")]
+        (n, W8) for n in ("qkv8", "o8", "gate_up8", "down8")] + [(n, P) for n in ("qkv8t", "o8t", "gate_up8t", "down8t")]
 
 
 class Decoder(C.Structure):
     _fields_ = [(n, I) for n in ("layers", "hidden", "Hq", "Hkv", "inter", "vocab", "sec0", "sec1", "head_dim",
                                  "gemma")] + [
-        ("eps", F), ("embed_scale", F), ("embed", P), ("lm_head", P), ("lm_head_t", P), ("final_norm_w", P), ("L", C.POINTER(DecLayer)),
+        ("eps", F), ("embed_scale", F), ("embed", P), ("lm_head", P), ("lm_head_t", P), ("lm_head8t", W8), ("final_norm_w", P), ("L", C.POINTER(DecLayer)),
         ("rope_cos", P), ("rope_sin", P), ("max_pos", I)]
 
 
@@ -118,6 +118,8 @@ _HIP_SIGS = {
     "hwocr_attn_decode_variant": ([I, I, I, C.c_char_p, I], I),
     "hwocr_decode_gemm_plan": ([C.POINTER(Decoder), I, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I)], I),
     "hwocr_tile_weights": ([P, P, I, I, I, P], I),
+    "hwocr_tile_weights_fp8": ([P, P, I, I, I, P], I),
+    "hwocr_gemm_skinny_w8": ([P, P, P, P, P, I, I, I, I, I, I, I, P], I),
     "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, I, P], I),
     "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, P], I),
     "hwocr_attn_decode_qkv": ([P, I, L, P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, I, I, P, P], I),

@@ -517,9 +517,17 @@ int skinny_nb(int Bsz) {  // batch tiles of the gemm_skinny_kernel instance that
 
 extern "C" int hwocr_gemm_skinny_variant(int Bsz, int N, int K, int epi, int splitk, int w_tiled, char* name, int name_len) {
   if (!name || name_len < 8 || !skinny_args_ok(Bsz, N, K, K, K, N, epi, splitk, false)) return HWOCR_EINVAL;
+  if (w_tiled == 2) {  // E4M3 weights (hwocr_gemm_skinny_w8): always the streaming kernel
+    if (K % 64) return HWOCR_EINVAL;
+    const char* v = nullptr;
+    const int rc = hwocr_gemm_stream_variant(Bsz, N, K, epi, splitk, true, &v);
+    if (rc != HWOCR_OK) return rc;
+    snprintf(name, name_len, "%s e4m3 epi=%d", v, epi);
+    return HWOCR_OK;
+  }
   if (skinny_takes_stream(Bsz, N, K, epi, splitk, w_tiled)) {
     const char* v = nullptr;
-    const int rc = hwocr_gemm_stream_variant(Bsz, N, K, epi, splitk, &v);
+    const int rc = hwocr_gemm_stream_variant(Bsz, N, K, epi, splitk, false, &v);
     if (rc != HWOCR_OK) return rc;
     snprintf(name, name_len, "%s epi=%d", v, epi);
     return HWOCR_OK;
@@ -553,4 +561,39 @@ extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias,
     case 12: return launch_skinny<12>(a, epi, splitk, w_tiled != 0, stream);
     default: return launch_skinny<16>(a, epi, splitk, w_tiled != 0, stream);
   }
+}
+
+// ---- decode GEMMs on E4M3 weights (BASELINE config 4): the codes of hwocr_quant_rows_fp8 re-laid in the order the streaming
+// kernel's DMAs and fragment reads want them.  [N][K] bytes -> [N/16][K/64][64 lanes][16 B]: lane (c = lane & 15, q = lane >> 4)
+// holds row 16 tile + c, k = 64 kt + 8 q + {0..7} and then k = 64 kt + 32 + 8 q + {0..7}.
+__global__ __launch_bounds__(256) void tile_weights_fp8_kernel(const unsigned char* src, unsigned char* dst, int N, int K, int ldw) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;  // one 16-byte granule each
+  const long total = (long)N * (K >> 4);
+  if (gid >= total) return;
+  const int lane = gid & 63;
+  const long blk = gid >> 6;  // (tile, k tile)
+  const int ktiles = K >> 6;
+  const int tile = blk / ktiles, kt = blk % ktiles;
+  const int c = lane & 15, q = lane >> 4;
+  const unsigned char* row = src + (size_t)(tile * 16 + c) * ldw + kt * 64 + q * 8;
+  uint2 lo = *(const uint2*)row, hi = *(const uint2*)(row + 32);
+  *(uint4*)(dst + gid * 16) = uint4{lo.x, lo.y, hi.x, hi.y};
+}
+
+extern "C" int hwocr_tile_weights_fp8(const void* src, void* dst, int N, int K, int ldw, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!src || !dst || N <= 0 || K <= 0 || (N % 16) || (K % 64) || (ldw % 8)) return HWOCR_EINVAL;
+  const long total = (long)N * (K >> 4);
+  hipLaunchKernelGGL(tile_weights_fp8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     (const unsigned char*)src, (unsigned char*)dst, N, K, ldw);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_gemm_skinny_w8(const void* X, const void* W8t, const float* wscale, const void* bias, void* out, int Bsz,
+                                    int N, int K, int ldx, int ldo, int epi, int splitk, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!X || !W8t || !wscale || !out || (K % 64) || !skinny_args_ok(Bsz, N, K, ldx, K, ldo, epi, splitk, bias != nullptr)) return HWOCR_EINVAL;
+  StreamArgs a{(const bf16*)X, (const bf16*)W8t, (const bf16*)bias, out, Bsz, N, K, ldx, ldo, 0};
+  a.wscale = wscale;
+  return hwocr_gemm_stream(a, epi, splitk, stream);
 }

@@ -122,10 +122,11 @@ __device__ __forceinline__ void tile_of_block(int tilesM, int tilesN, int group,
 struct StreamArgs {
   const bf16* X; const bf16* W; const bf16* bias; void* out;
   int Bsz, N, K, ldx, ldo, ktiles_per_slice;
+  const float* wscale = nullptr;  // non-NULL: W holds E4M3 codes in the byte-tiled layout (hwocr_tile_weights_fp8), one scale per feature
 };
 int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream);
 // the kernel instance hwocr_gemm_stream would run for this shape (static string), without launching anything
-int hwocr_gemm_stream_variant(int Bsz, int N, int K, int epi, int splitk, const char** name);
+int hwocr_gemm_stream_variant(int Bsz, int N, int K, int epi, int splitk, bool w8, const char** name);
 
 // the fused vision QKV form is taken when the attention width is whole 256-wide tiles (no tile mixes q, k and v), the rotary
 // pairs of a head fall into 16-byte pieces and there are enough rows for the 256x256 kernel

@@ -47,8 +47,8 @@ constexpr int WAVES = 16;
 constexpr int WBYTES = WG_TILES * 2048;    // one K tile (64) of 16 weight tiles' fragments
 // stages of the ring of gemm_stream_kernel<MT, ., ., WT>: as many 64-wide K tiles (x tile + WT weight-tile slots) as fit in
 // 160 KiB, at most 6 (wait_dma counts up to 15 outstanding instructions: 3 per K tile and wave)
-constexpr int stream_stages(int MT, int WT) {
-  const int stage = 2 * MT * 1024 + WT * 2048;
+constexpr int stream_stages(int MT, int WT, bool W8 = false) {
+  const int stage = 2 * MT * 1024 + WT * (W8 ? 1024 : 2048);
   const int n = (160 * 1024) / stage;
   return n > 6 ? 6 : n;
 }
@@ -80,6 +80,17 @@ __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of t
   }
 }
 
+// 8 E4M3 codes (two dwords) -> the bf16 fragment they stand for: every E4M3 value is exactly representable in bf16, so the
+// decode GEMMs of the fp8 configuration multiply exactly the stored codes (the per-feature scale goes into the epilogue).
+__device__ __forceinline__ bf16x8 e4m3x8_to_bf16(int lo, int hi) {
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+  bf16x8 o;
+  o[0] = f2bf(a[0]); o[1] = f2bf(a[1]); o[2] = f2bf(b[0]); o[3] = f2bf(b[1]);
+  o[4] = f2bf(c[0]); o[5] = f2bf(c[1]); o[6] = f2bf(d[0]); o[7] = f2bf(d[1]);
+  return o;
+}
+
 // MT: 16-row activation tiles (Bsz <= 16 MT).  16 waves = MSPLIT (row halves) x 16/MSPLIT (tile groups): a wave multiplies
 // MT/MSPLIT row tiles by MSPLIT weight tiles.  MSPLIT = 2 halves the x fragments every wave has to read from LDS (all 16
 // waves reading the whole x tile is 288 KB of ds_read per K tile at 128 rows - as long as the DMA of that K tile takes).
@@ -90,9 +101,13 @@ __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of t
 // tiles over 256 / splitk groups) are what pays for a third and fourth stage.  Why it exists beside gemm_stream256_kernel:
 // that kernel's loop SKELETON (counted wait + 16-wave barrier + DMA issue per 32-wide K tile) measures 31 of the 41 us of the 2B
 // gate/up GEMM with every byte and every MFMA removed; 64-wide K tiles halve the number of trips.
-template <int MT, int EPI, int MSPLIT, int WT = WG_TILES>
+// W8: the weights are E4M3 codes in the byte-tiled layout of hwocr_tile_weights_fp8 ([N/16][K/64][lane][16 B] = a lane's 8
+// codes of the first 32-wide half of the K tile, then of the second): ONE 1-KiB DMA per weight tile and K tile (half the bytes
+// entering the CU for the weights), converted to bf16 fragments in registers; a.wscale[n] scales output feature n.
+template <int MT, int EPI, int MSPLIT, int WT = WG_TILES, bool W8 = false>
 __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
-  constexpr int WBYTES = WT * 2048;                 // (shadows the 16-tile constant)
+  constexpr int WSLOT = W8 ? 1024 : 2048;           // bytes of one weight tile's K tile
+  constexpr int WBYTES = WT * WSLOT;                // (shadows the 16-tile constant)
   constexpr int NWN = WAVES / MSPLIT;               // waves along N
   constexpr int NTW = WG_TILES / NWN;               // weight tiles per wave (= MSPLIT)
   constexpr int MTW = MT / MSPLIT;                  // row tiles per wave
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
   constexpr int XPW = (XFR + WAVES - 1) / WAVES;    // staged per wave
   constexpr int XBYTES = XFR * 1024;
   constexpr int STAGE = XBYTES + WBYTES;
-  constexpr int NSTAGE = stream_stages(MT, WT);
+  constexpr int NSTAGE = stream_stages(MT, WT, W8);
   static_assert(NSTAGE * STAGE <= 160 * 1024, "ring does not fit in LDS");
   constexpr int DIST = NSTAGE - 1;                  // K tiles in flight ahead of the one being multiplied
   static_assert(MT % MSPLIT == 0 && (MSPLIT == 1 || MSPLIT == 2), "row tiles split evenly over the wave rows");
@@ -130,8 +145,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
     const int f = w + WAVES * e;
     xsrc[e] = a.X + (size_t)min(r0 + 8 * f + (lane >> 3), a.Bsz - 1) * a.ldx + (size_t)kt0 * 64 + 8 * ((lane & 7) ^ (lane >> 3));
   }
-  const bf16* wsrc = a.W + ((size_t)(t0 + w) * (a.K >> 5) + (size_t)kt0 * 2) * 512 + lane * 8;  // + t*1024 + h*512
-  const int n_dma = (XFR > w ? (XFR - w + WAVES - 1) / WAVES : 0) + (stage_w ? 2 : 0);  // DMA instructions per stage
+  // bf16: + t*1024 + h*512 elements; E4M3: a K tile of a weight tile is 1024 bytes = 512 "elements" of this pointer type
+  const bf16* wsrc = W8 ? a.W + ((size_t)(t0 + w) * (a.K >> 6) + (size_t)kt0) * 512 + lane * 8
+                        : a.W + ((size_t)(t0 + w) * (a.K >> 5) + (size_t)kt0 * 2) * 512 + lane * 8;
+  const int n_dma = (XFR > w ? (XFR - w + WAVES - 1) / WAVES : 0) + (stage_w ? (W8 ? 1 : 2) : 0);  // DMA instructions per stage
 
   auto issue = [&](int t) {
     char* st = smem + (t % NSTAGE) * STAGE;
@@ -140,10 +157,14 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
       if (w + WAVES * e < XFR)
         __builtin_amdgcn_global_load_lds((const void*)(xsrc[e] + t * 64), LDS_PTR(st + (w + WAVES * e) * 1024), 16, 0, 0);
     if (stage_w) {
-      const bf16* s = wsrc + (size_t)t * 1024;
-      char* d = st + XBYTES + w * 2048;
-      __builtin_amdgcn_global_load_lds((const void*)s, LDS_PTR(d), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const void*)(s + 512), LDS_PTR(d + 1024), 16, 0, 0);
+      if constexpr (W8) {
+        __builtin_amdgcn_global_load_lds((const void*)(wsrc + (size_t)t * 512), LDS_PTR(st + XBYTES + w * 1024), 16, 0, 0);
+      } else {
+        const bf16* s = wsrc + (size_t)t * 1024;
+        char* d = st + XBYTES + w * 2048;
+        __builtin_amdgcn_global_load_lds((const void*)s, LDS_PTR(d), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(s + 512), LDS_PTR(d + 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -172,7 +193,14 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
         for (int i = 0; i < MTW; ++i)
           xh[i] = *(const bf16x8*)(st + (16 * (wm * MTW + i) + c) * 128 + (((4 * h + q) ^ (c & 7)) << 4));
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) wh[j] = *(const bf16x8*)(st + XBYTES + (wn * NTW + j) * 2048 + h * 1024 + lane * 16);
+        for (int j = 0; j < NTW; ++j) {
+          if constexpr (W8) {
+            const int2 raw = *(const int2*)(st + XBYTES + (wn * NTW + j) * 1024 + lane * 16 + h * 8);
+            wh[j] = e4m3x8_to_bf16(raw.x, raw.y);
+          } else {
+            wh[j] = *(const bf16x8*)(st + XBYTES + (wn * NTW + j) * 2048 + h * 1024 + lane * 16);
+          }
+        }
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
           if (j < mine) {
@@ -189,9 +217,16 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
       for (int h = 0; h < 2; ++h)
         xf[i][h] = *(const bf16x8*)(st + (16 * (wm * MTW + i) + c) * 128 + (((4 * h + q) ^ (c & 7)) << 4));
 #pragma unroll
-    for (int j = 0; j < NTW; ++j)
+    for (int j = 0; j < NTW; ++j) {
+      if constexpr (W8) {
+        const int4 raw = *(const int4*)(st + XBYTES + (wn * NTW + j) * 1024 + lane * 16);
+        wf[j][0] = e4m3x8_to_bf16(raw.x, raw.y);
+        wf[j][1] = e4m3x8_to_bf16(raw.z, raw.w);
+      } else {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) wf[j][h] = *(const bf16x8*)(st + XBYTES + (wn * NTW + j) * 2048 + h * 1024 + lane * 16);
+        for (int h = 0; h < 2; ++h) wf[j][h] = *(const bf16x8*)(st + XBYTES + (wn * NTW + j) * 2048 + h * 1024 + lane * 16);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
       if (j < mine) {
@@ -203,6 +238,17 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream_kernel(StreamArgs a) {
       }
   }
 
+  if constexpr (W8) {  // per-output-feature scale of the E4M3 codes
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+      if (j < mine) {
+        const f32x4 sc = *(const f32x4*)(a.wscale + 16 * (my0 + j) + 4 * q);
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[j][i][r] *= sc[r];
+      }
+  }
   // ---- epilogue: lane (c,q): acc[j][i][r] = out[16 (wm MTW + i) + c][16 (my0 + j) + 4 q + r]
   if constexpr (is_glu<EPI> && NTW == 1) {
     // gate tile in the even wave, up tile in the odd one: the up accumulators cross through the (now idle) ring
@@ -372,29 +418,33 @@ void launch256(const StreamArgs& a, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((gemm_stream256_kernel<EPI>), grid, dim3(64 * WAVES), LDS, st, a);
 }
 
-template <int MT, int EPI, int MSPLIT, int WT>
+template <int MT, int EPI, int MSPLIT, int WT, bool W8>
 void launch_one(const StreamArgs& a, dim3 grid, hipStream_t st) {
-  constexpr int STAGE = 2 * MT * 1024 + WT * 2048;
-  constexpr int LDS = stream_stages(MT, WT) * STAGE;
+  constexpr int STAGE = 2 * MT * 1024 + WT * (W8 ? 1024 : 2048);
+  constexpr int LDS = stream_stages(MT, WT, W8) * STAGE;
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<MT, EPI, MSPLIT, WT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<MT, EPI, MSPLIT, WT, W8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDS);
     done = true;
   }
-  hipLaunchKernelGGL((gemm_stream_kernel<MT, EPI, MSPLIT, WT>), grid, dim3(64 * WAVES), LDS, st, a);
+  hipLaunchKernelGGL((gemm_stream_kernel<MT, EPI, MSPLIT, WT, W8>), grid, dim3(64 * WAVES), LDS, st, a);
 }
 
-template <int MT, int MSPLIT, int WT = WG_TILES>
-int launch_mt(const StreamArgs& a, int epi, dim3 grid, hipStream_t st) {
+template <int MT, int MSPLIT, int WT, bool W8>
+int launch_epi(const StreamArgs& a, int epi, dim3 grid, hipStream_t st) {
   switch (epi) {
-    case EPI_LINEAR: launch_one<MT, EPI_LINEAR, MSPLIT, WT>(a, grid, st); break;
-    case EPI_SWIGLU: launch_one<MT, EPI_SWIGLU, MSPLIT, WT>(a, grid, st); break;
-    case EPI_GEGLU: launch_one<MT, EPI_GEGLU, MSPLIT, WT>(a, grid, st); break;
-    case EPI_PARTIAL: launch_one<MT, EPI_PARTIAL, MSPLIT, WT>(a, grid, st); break;
+    case EPI_LINEAR: launch_one<MT, EPI_LINEAR, MSPLIT, WT, W8>(a, grid, st); break;
+    case EPI_SWIGLU: launch_one<MT, EPI_SWIGLU, MSPLIT, WT, W8>(a, grid, st); break;
+    case EPI_GEGLU: launch_one<MT, EPI_GEGLU, MSPLIT, WT, W8>(a, grid, st); break;
+    case EPI_PARTIAL: launch_one<MT, EPI_PARTIAL, MSPLIT, WT, W8>(a, grid, st); break;
     default: return HWOCR_EINVAL;
   }
   return hwocr_launch_status();
+}
+template <int MT, int MSPLIT, int WT = WG_TILES>
+int launch_mt(const StreamArgs& a, int epi, dim3 grid, hipStream_t st) {
+  return a.wscale ? launch_epi<MT, MSPLIT, WT, true>(a, epi, grid, st) : launch_epi<MT, MSPLIT, WT, false>(a, epi, grid, st);
 }
 
 }  // namespace
@@ -403,14 +453,16 @@ int launch_mt(const StreamArgs& a, int epi, dim3 grid, hipStream_t st) {
 // The choice of kernel instance and grid is made by plan_stream alone, so that hwocr_gemm_stream_variant (what the parity
 // tests ask: "which instance would this call run?") and the launcher cannot disagree.
 namespace {
-enum StreamKind : int { SK_MT1, SK_MT2, SK_MT4, SK_MT8_M1, SK_MT8_M2, SK_MT8_M2_R2, SK_K64_W8, SK_K64_W10, SK_K32_256 };
+enum StreamKind : int { SK_MT1, SK_MT2, SK_MT4, SK_MT8_M1, SK_MT8_M2, SK_MT8_M2_R2, SK_K64_W8, SK_K64_W10, SK_K32_256, SK_K64_W16 };
 const char* const kStreamKindName[] = {
     "gemm_stream_kernel<1,1,16>",        "gemm_stream_kernel<2,1,16>",  "gemm_stream_kernel<4,1,16>",
     "gemm_stream_kernel<8,1,16>",        "gemm_stream_kernel<8,2,16>",  "gemm_stream_kernel<8,2,16>/rowblocks2",
-    "gemm_stream_kernel<16,2,8>",        "gemm_stream_kernel<16,2,10>", "gemm_stream256_kernel"};
+    "gemm_stream_kernel<16,2,8>",        "gemm_stream_kernel<16,2,10>", "gemm_stream256_kernel", "gemm_stream_kernel<16,2,16>"};
 struct StreamPlan { int kind; dim3 grid; int ktiles_per_slice; };
 
-int plan_stream(int Bsz, int N, int K, int epi, int splitk, StreamPlan& p) {
+// w8: E4M3 weights (a weight tile's K tile is 1 KiB instead of 2): the 16-slot form fits three stages at 129..256 rows too, so
+// the 32-wide-K kernel is never needed
+int plan_stream(int Bsz, int N, int K, int epi, int splitk, bool w8, StreamPlan& p) {
   if (Bsz < 1 || Bsz > 256 || (K % 64) || (N % 16) || splitk < 1) return HWOCR_EINVAL;
   if (epi != EPI_LINEAR && epi != EPI_SWIGLU && epi != EPI_GEGLU && epi != EPI_PARTIAL) return HWOCR_EINVAL;
   const int ktiles = K / 64;
@@ -453,21 +505,21 @@ int plan_stream(int Bsz, int N, int K, int epi, int splitk, StreamPlan& p) {
   }
   if (k64 && tiles_per_wg <= 8) { p.kind = SK_K64_W8; return HWOCR_OK; }
   if (k64 && tiles_per_wg <= 10) { p.kind = SK_K64_W10; return HWOCR_OK; }  // 52 KiB stages, 3 of them (7B gate/up: 5 pairs)
-  p.kind = SK_K32_256;
+  p.kind = w8 ? SK_K64_W16 : SK_K32_256;
   return HWOCR_OK;
 }
 }  // namespace
 
-int hwocr_gemm_stream_variant(int Bsz, int N, int K, int epi, int splitk, const char** name) {
+int hwocr_gemm_stream_variant(int Bsz, int N, int K, int epi, int splitk, bool w8, const char** name) {
   StreamPlan p;
-  const int rc = plan_stream(Bsz, N, K, epi, splitk, p);
+  const int rc = plan_stream(Bsz, N, K, epi, splitk, w8, p);
   if (rc == HWOCR_OK && name) *name = kStreamKindName[p.kind];
   return rc;
 }
 
 int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
   StreamPlan p;
-  const int rc = plan_stream(a.Bsz, a.N, a.K, epi, splitk, p);
+  const int rc = plan_stream(a.Bsz, a.N, a.K, epi, splitk, a.wscale != nullptr, p);
   if (rc != HWOCR_OK) return rc;
   a.ktiles_per_slice = p.ktiles_per_slice;
   switch (p.kind) {
@@ -479,8 +531,10 @@ int hwocr_gemm_stream(StreamArgs a, int epi, int splitk, hipStream_t stream) {
     case SK_MT8_M2_R2: return launch_mt<8, 2>(a, epi, p.grid, stream);
     case SK_K64_W8: return launch_mt<16, 2, 8>(a, epi, p.grid, stream);
     case SK_K64_W10: return launch_mt<16, 2, 10>(a, epi, p.grid, stream);
+    case SK_K64_W16: return launch_epi<16, 2, 16, true>(a, epi, p.grid, stream);  // E4M3 weights only (48 KiB stages)
     default: break;
   }
+  if (a.wscale) return HWOCR_EINVAL;  // the 32-wide-K kernel has no E4M3 form (never planned for one)
   switch (epi) {
     case EPI_LINEAR: launch256<EPI_LINEAR>(a, p.grid, stream); break;
     case EPI_SWIGLU: launch256<EPI_SWIGLU>(a, p.grid, stream); break;

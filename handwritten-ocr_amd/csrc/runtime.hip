@@ -166,6 +166,13 @@ extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, con
   return HWOCR_OK;
 }
 
+// one decode GEMM: E4M3 weights when the layer carries a byte-tiled copy, else the fragment-tiled bf16 copy, else row-major
+static int decode_gemm(const void* x, const void* w, const void* wt, const void* w8t, const float* w8s, void* out, int nseq, int N,
+                       int K, int ldo, int epi, int splitk, hipStream_t st) {
+  if (w8t && w8s) return hwocr_gemm_skinny_w8(x, w8t, w8s, nullptr, out, nseq, N, K, K, ldo, epi, splitk, st);
+  return hwocr_gemm_skinny(x, wt ? wt : w, nullptr, out, nseq, N, K, K, K, ldo, epi, splitk, wt != nullptr, st);
+}
+
 extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
                              const hwocr_gen_state* gs, const int* ids, const int* img_row, const void* img_embeds,
                              const int* pos3, const int* seq_lens, const int* last_rows, int nseq, int rows_per_seq,
@@ -213,8 +220,8 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
   // final norm on the last prompt token of every read -> LM head -> first generated token
   CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->final_norm_w, ws->hn, Hd, last_rows, nseq, Hd,
                           m->eps, G, st));
-  CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head_t ? m->lm_head_t : m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd,
-                          Hd, m->vocab, HWOCR_EPI_LINEAR, 1, m->lm_head_t != nullptr, st));
+  CHECK(decode_gemm(ws->hn, m->lm_head, m->lm_head_t, m->lm_head8t.w, m->lm_head8t.scale, ws->logits, nseq, m->vocab, Hd, m->vocab,
+                    HWOCR_EPI_LINEAR, 1, st));  // the same LM head (bf16 or E4M3) as every later step
   CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids + seq0, gs->lens + seq0,
                              gs->n_gen + seq0, gs->finished + seq0, gs->out_tokens + (long)seq0 * gs->max_new,
                              gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id,
@@ -227,7 +234,8 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
 static void decode_splits(const hwocr_decoder* m, int nseq, int& s_qkv, int& s_o, int& s_d) {
   const int HD = m->head_dim, Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
   bool stream = (Hd % 64) == 0 && (OW % 64) == 0 && (m->inter % 64) == 0;
-  for (int l = 0; l < m->layers && stream; ++l) stream = m->L[l].qkv_wt && m->L[l].o_wt && m->L[l].down_wt;
+  for (int l = 0; l < m->layers && stream; ++l)
+    stream = (m->L[l].qkv_wt || m->L[l].qkv8t) && (m->L[l].o_wt || m->L[l].o8t) && (m->L[l].down_wt || m->L[l].down8t);
   s_qkv = stream ? pick_splitk_stream(Hd, QW, nseq) : pick_splitk(Hd, QW, 400);
   s_o = stream ? pick_splitk_stream(OW, Hd, nseq) : pick_splitk(OW, Hd, 400);
   s_d = stream ? pick_splitk_stream(m->inter, Hd, nseq) : pick_splitk(m->inter, Hd, 400);
@@ -245,12 +253,13 @@ extern "C" int hwocr_decode_gemm_plan(const hwocr_decoder* m, int nseq, int whic
   decode_splits(m, nseq, s_qkv, s_o, s_d);
   const hwocr_dec_layer& L = m->L[0];
   switch (which) {
-    case 0: *N = QW, *K = Hd, *epi = HWOCR_EPI_PARTIAL, *splitk = s_qkv, *w_tiled = L.qkv_wt != nullptr; break;
-    case 1: *N = Hd, *K = OW, *epi = HWOCR_EPI_PARTIAL, *splitk = s_o, *w_tiled = L.o_wt != nullptr; break;
+    case 0: *N = QW, *K = Hd, *epi = HWOCR_EPI_PARTIAL, *splitk = s_qkv, *w_tiled = L.qkv8t ? 2 : L.qkv_wt != nullptr; break;
+    case 1: *N = Hd, *K = OW, *epi = HWOCR_EPI_PARTIAL, *splitk = s_o, *w_tiled = L.o8t ? 2 : L.o_wt != nullptr; break;
     case 2: *N = 2 * m->inter, *K = Hd, *epi = m->gemma ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, *splitk = 1,
-            *w_tiled = L.gate_up_wt != nullptr; break;
-    case 3: *N = Hd, *K = m->inter, *epi = HWOCR_EPI_PARTIAL, *splitk = s_d, *w_tiled = L.down_wt != nullptr; break;
-    default: *N = m->vocab, *K = Hd, *epi = HWOCR_EPI_LINEAR, *splitk = 1, *w_tiled = m->lm_head_t != nullptr; break;
+            *w_tiled = L.gate_up8t ? 2 : L.gate_up_wt != nullptr; break;
+    case 3: *N = Hd, *K = m->inter, *epi = HWOCR_EPI_PARTIAL, *splitk = s_d, *w_tiled = L.down8t ? 2 : L.down_wt != nullptr; break;
+    default: *N = m->vocab, *K = Hd, *epi = HWOCR_EPI_LINEAR, *splitk = 1,
+             *w_tiled = m->lm_head8t.w ? 2 : m->lm_head_t != nullptr; break;
   }
   return HWOCR_OK;
 }
@@ -273,8 +282,7 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
     const hwocr_dec_layer& L = m->L[l];
     bf16* Kc = B(kv->k) + l * k_layer;
     bf16* Vc = B(kv->vt) + l * k_layer;
-    CHECK(hwocr_gemm_skinny(ws->hn, L.qkv_wt ? L.qkv_wt : L.qkv_w, nullptr, ws->slabs, nseq, QW, Hd, Hd, Hd, QW,
-                            HWOCR_EPI_PARTIAL, s_qkv, L.qkv_wt != nullptr, st));
+    CHECK(decode_gemm(ws->hn, L.qkv_w, L.qkv_wt, L.qkv8t, L.qkv8.scale, ws->slabs, nseq, QW, Hd, QW, HWOCR_EPI_PARTIAL, s_qkv, st));
     // bias + rotary + cache append of this step's q / k / v ride in the attention launch (one launch per layer less;
     // HWOCR_DECODE_FUSE_QKV=0: the two separate launches, for A/B runs)
     static const bool fuse_qkv = [] { const char* e = getenv("HWOCR_DECODE_FUSE_QKV"); return !e || atoi(e) != 0; }();
@@ -288,20 +296,19 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
     CHECK(hwocr_attn_decode_qkv(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, Kc, Vc, gs->lens, gs->rope_delta, m->rope_cos,
                                 m->rope_sin, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv, attn_splits, k_seq, k_head,
                                 k_seq, k_head, kv->ctx, scale, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
-    CHECK(hwocr_gemm_skinny(ws->attn, L.o_wt ? L.o_wt : L.o_w, nullptr, ws->slabs, nseq, Hd, OW, OW, OW, Hd,
-                            HWOCR_EPI_PARTIAL, s_o, L.o_wt != nullptr, st));
+    CHECK(decode_gemm(ws->attn, L.o_w, L.o_wt, L.o8t, L.o8.scale, ws->slabs, nseq, Hd, OW, Hd, HWOCR_EPI_PARTIAL, s_o, st));
     CHECK(hwocr_add_rmsnorm(ws->slabs, s_o, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd,
                             nullptr, nseq, Hd, m->eps, G, st));
-    CHECK(hwocr_gemm_skinny(ws->hn, L.gate_up_wt ? L.gate_up_wt : L.gate_up_w, nullptr, ws->act, nseq, 2 * m->inter, Hd,
-                            Hd, Hd, m->inter, G ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, 1, L.gate_up_wt != nullptr, st));
-    CHECK(hwocr_gemm_skinny(ws->act, L.down_wt ? L.down_wt : L.down_w, nullptr, ws->slabs, nseq, Hd, m->inter, m->inter,
-                            m->inter, Hd, HWOCR_EPI_PARTIAL, s_d, L.down_wt != nullptr, st));
+    CHECK(decode_gemm(ws->hn, L.gate_up_w, L.gate_up_wt, L.gate_up8t, L.gate_up8.scale, ws->act, nseq, 2 * m->inter, Hd, m->inter,
+                      G ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, 1, st));
+    CHECK(decode_gemm(ws->act, L.down_w, L.down_wt, L.down8t, L.down8.scale, ws->slabs, nseq, Hd, m->inter, Hd, HWOCR_EPI_PARTIAL, s_d,
+                      st));
     const void* next_norm = (l + 1 < m->layers) ? m->L[l + 1].in_norm_w : m->final_norm_w;
     CHECK(hwocr_add_rmsnorm(ws->slabs, s_d, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, next_norm, ws->hn, Hd, nullptr,
                             nseq, Hd, m->eps, G, st));
   }
-  CHECK(hwocr_gemm_skinny(ws->hn, m->lm_head_t ? m->lm_head_t : m->lm_head, nullptr, ws->logits, nseq, m->vocab, Hd, Hd,
-                          Hd, m->vocab, HWOCR_EPI_LINEAR, 1, m->lm_head_t != nullptr, st));
+  CHECK(decode_gemm(ws->hn, m->lm_head, m->lm_head_t, m->lm_head8t.w, m->lm_head8t.scale, ws->logits, nseq, m->vocab, Hd, m->vocab,
+                    HWOCR_EPI_LINEAR, 1, st));
   CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished,
                              gs->out_tokens, gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, gs->seen, gs->seen_ld,
                              gs->rep_penalty, st));

@@ -361,15 +361,23 @@ def pick_attn_splits(reads: int, kv_heads: int) -> int:
 DECODE_GEMMS = ("qkv", "o", "gate_up", "down", "lm_head")
 
 
-def decode_plan(cfg: ModelConfig, reads: int) -> dict:
+def decode_plan(cfg: ModelConfig, reads: int, fp8: bool = False) -> dict:
     """Kernel instances one decode step of `cfg` runs at `reads` reads in flight: {gemm name: (N, K, epi, splitk, variant)}
-    for the five GEMMs + "attn": variant.  Host-only (asks the library's own launch planner; nothing is launched)."""
+    for the five GEMMs + "attn": variant.  fp8: the engine was built with fp8=True (E4M3 decode weights).  Host-only (asks the
+    library's own launch planner; nothing is launched)."""
     lib = _lib.hip()
     layer = (_lib.DecLayer * 1)()
-    one = C.c_void_p(1)  # non-NULL: the engine always binds the fragment-tiled copies
-    layer[0].qkv_wt = layer[0].o_wt = layer[0].gate_up_wt = layer[0].down_wt = one
+    one = C.c_void_p(1)  # non-NULL: the engine always binds one tiled copy of every decode weight
+    if fp8:
+        layer[0].qkv8t = layer[0].o8t = layer[0].gate_up8t = layer[0].down8t = one
+    else:
+        layer[0].qkv_wt = layer[0].o_wt = layer[0].gate_up_wt = layer[0].down_wt = one
     dec = _lib.Decoder(layers=1, hidden=cfg.hidden, Hq=cfg.q_heads, Hkv=cfg.kv_heads, inter=cfg.inter, vocab=cfg.vocab,
-                       head_dim=cfg.head_dim, gemma=1 if cfg.family == "paligemma" else 0, lm_head_t=one, L=layer)
+                       head_dim=cfg.head_dim, gemma=1 if cfg.family == "paligemma" else 0, L=layer)
+    if fp8:
+        dec.lm_head8t = _lib.W8(w=one, scale=one)
+    else:
+        dec.lm_head_t = one
     out = {}
     buf = C.create_string_buffer(128)
     for which, name in enumerate(DECODE_GEMMS):
@@ -445,7 +453,20 @@ class ReadEngine:
         _lib.check(self.lib.hwocr_quant_rows_fp8(_lib.ptr(w2d), _lib.ptr(q), _lib.ptr(s), n, k, k, k, _lib.stream_handle()),
                    "hwocr_quant_rows_fp8")
         self._keep += [q, s]
-        return _lib.W8(w=_lib.ptr(q), scale=_lib.ptr(s))
+        pack = _lib.W8(w=_lib.ptr(q), scale=_lib.ptr(s))
+        pack.codes, pack.scales = q, s  # (python-side handles for the decode re-tiling below)
+        return pack
+
+    def _w8_tiled(self, pack: _lib.W8):
+        """Byte-tiled copy of an E4M3 weight for the decode GEMMs (hwocr_tile_weights_fp8), or None."""
+        q = getattr(pack, "codes", None)
+        if q is None or q.shape[0] % 16 or q.shape[1] % 64 or os.environ.get("HWOCR_FP8_DECODE", "1") == "0":  # (=0: A/B switch)
+            return None
+        n, k = q.shape
+        out = torch.empty(n * k, dtype=torch.uint8, device=self.dev)
+        _lib.check(self.lib.hwocr_tile_weights_fp8(_lib.ptr(q), _lib.ptr(out), n, k, k, _lib.stream_handle()), "hwocr_tile_weights_fp8")
+        self._tiled_keep.append(out)
+        return _lib.ptr(out)
 
     def _bind_weights(self, sd: dict) -> None:
         if self.cfg.family == "paligemma":
@@ -604,10 +625,16 @@ class ReadEngine:
             L.o_w = P(w_o)
             L.post_norm_w = P(self._t(sd[p + "post_attention_layernorm.weight"]))
             L.gate_up_w, L.down_w = P(w_gu), P(w_down)
-            # decode copies in MFMA-fragment order (contiguous KiB per fragment load; 288 GB of HBM pays for the copy)
-            L.qkv_wt, L.o_wt = P(self._tiled(w_qkv)), P(self._tiled(w_o))
-            L.gate_up_wt, L.down_wt = P(self._tiled(w_gu)), P(self._tiled(w_down))
             L.qkv8, L.o8, L.gate_up8, L.down8 = self._w8(w_qkv), self._w8(w_o), self._w8(w_gu), self._w8(w_down)
+            # decode copies: E4M3 codes byte-tiled for the streaming kernel where the layer has them (fp8 mode: half the weight
+            # bytes per decode step), else bf16 in MFMA-fragment order (contiguous KiB per fragment load; 288 GB of HBM pays
+            # for the copy)
+            for name, w, pack in (("qkv", w_qkv, L.qkv8), ("o", w_o, L.o8), ("gate_up", w_gu, L.gate_up8), ("down", w_down, L.down8)):
+                t8 = self._w8_tiled(pack)
+                if t8 is not None:
+                    setattr(L, name + "8t", t8)
+                else:
+                    setattr(L, name + "_wt", P(self._tiled(w)))
         embed = self._t(sd[t + "embed_tokens.weight"])
         head = embed if (c.tie or "lm_head.weight" not in sd) else self._t(sd["lm_head.weight"])
         inv = 1.0 / (c.rope_theta ** (torch.arange(0, HD, 2, dtype=torch.float) / HD))
@@ -620,8 +647,15 @@ class ReadEngine:
         self.dec = _lib.Decoder(layers=c.layers, hidden=c.hidden, Hq=c.q_heads, Hkv=c.kv_heads, inter=c.inter, vocab=c.vocab,
                                 sec0=sec0, sec1=sec1, head_dim=HD, gemma=1 if gemma else 0, eps=c.eps,
                                 embed_scale=float(c.hidden) ** 0.5,
-                                embed=P(embed), lm_head=P(head), lm_head_t=P(self._tiled(head)), final_norm_w=P(self._t(sd[t + "norm.weight"])), L=layers,
+                                embed=P(embed), lm_head=P(head), final_norm_w=P(self._t(sd[t + "norm.weight"])), L=layers,
                                 rope_cos=P(self.dec_cos), rope_sin=P(self.dec_sin), max_pos=int(ang.shape[0]))
+        head8 = self._w8(head)
+        head8t = self._w8_tiled(head8)
+        if head8t is not None:
+            self.dec.lm_head8t = _lib.W8(w=head8t, scale=head8.scale)
+            self._keep.append(head8)
+        else:
+            self.dec.lm_head_t = P(self._tiled(head))
         self._keep.append(layers)
         self.embed_weight = embed
 

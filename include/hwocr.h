@@ -71,8 +71,19 @@ int hwocr_gemm_wide_fp8(const void* X8, const float* xscale, const void* W8, con
 int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out, int Bsz, int N, int K, int ldx,
                       int ldw, int ldo, int epi, int splitk, int w_tiled, hwocr_stream_t stream);
 
+/* The decode GEMMs on E4M3 weights (BASELINE config 4, "fp8 ... on CDNA4"; no reference counterpart — HF runs bf16).  A decode
+ * step at <= 256 rows is bound by the bytes entering the compute units, not by the matrix pipes, so the weights are STORED as E4M3
+ * codes + one fp32 scale per output feature (hwocr_quant_rows_fp8) and multiplied as the bf16 values they stand for (every E4M3
+ * value is exact in bf16) against the bf16 activations: out = epi(wscale[n] * sum_k X[m][k] * e4m3(W8[n][k])), fp32 accumulation —
+ * half the weight bytes of hwocr_gemm_skinny, no activation quantisation.  hwocr_tile_weights_fp8: [N][K] code bytes ->
+ * [N/16][K/64][64 lanes][16 B], the order of the streaming kernel's DMAs (N % 16 == 0, K % 64 == 0).  epi / splitk as
+ * hwocr_gemm_skinny (PARTIAL slabs carry the scale already). */
+int hwocr_tile_weights_fp8(const void* src, void* dst, int N, int K, int ldw, hwocr_stream_t stream);
+int hwocr_gemm_skinny_w8(const void* X, const void* W8t, const float* wscale, const void* bias, void* out, int Bsz, int N, int K,
+                         int ldx, int ldo, int epi, int splitk, hwocr_stream_t stream);
+
 /* Name of the kernel instance the call hwocr_gemm_skinny(Bsz, N, K, epi, splitk, w_tiled) would launch (ldx = ldw = K,
- * ldo = N), written NUL-terminated into name[name_len]; launches nothing and needs no device.  The decode GEMMs pick among
+ * ldo = N; w_tiled == 2: hwocr_gemm_skinny_w8), written NUL-terminated into name[name_len]; launches nothing and needs no device.  The decode GEMMs pick among
  * several instances by shape (csrc/gemm_stream.hip plan_stream): the parity tests use this to prove that every instance a
  * shipped configuration dispatches has an oracle case. */
 int hwocr_gemm_skinny_variant(int Bsz, int N, int K, int epi, int splitk, int w_tiled, char* name, int name_len);
@@ -238,7 +249,8 @@ int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, const void* im
 typedef struct {
   const void *in_norm_w, *qkv_w, *qkv_b, *o_w, *post_norm_w, *gate_up_w, *down_w;
   const void *qkv_wt, *o_wt, *gate_up_wt, *down_wt; /* fragment-tiled copies for decode (NULL: use the row-major ones) */
-  hwocr_w8 qkv8, o8, gate_up8, down8; /* optional E4M3 copies for the prefill GEMMs (decode steps stay bf16) */
+  hwocr_w8 qkv8, o8, gate_up8, down8; /* optional E4M3 copies for the prefill GEMMs (row-major codes + per-feature scales) */
+  const void *qkv8t, *o8t, *gate_up8t, *down8t; /* the same codes byte-tiled for decode (hwocr_tile_weights_fp8; scales: above), or NULL */
 } hwocr_dec_layer;
 
 typedef struct {
@@ -250,6 +262,7 @@ typedef struct {
   const void* embed;        /* [vocab][hidden] */
   const void* lm_head;      /* [vocab][hidden] (may alias embed) */
   const void* lm_head_t;    /* fragment-tiled copy of lm_head for decode (may be NULL) */
+  hwocr_w8 lm_head8t;       /* E4M3 LM head for decode: byte-tiled codes (hwocr_tile_weights_fp8) + per-row scales, or {NULL, NULL} */
   const void* final_norm_w;
   const hwocr_dec_layer* L; /* host array[layers] */
   const void *rope_cos, *rope_sin; /* bf16 [max_pos][head_dim/2] */
@@ -291,8 +304,8 @@ int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwoc
                       int nseq, int attn_splits, hwocr_stream_t stream);
 
 /* The GEMM calls one hwocr_decode_step makes (layer 0; every layer has the same shapes), as arguments of hwocr_gemm_skinny:
- * which = 0 qkv, 1 o, 2 gate/up, 3 down, 4 LM head.  Only m's dimensions and the NULL-ness of the tiled weight pointers of
- * m->L[0] / m->lm_head_t are read.  Launches nothing. */
+ * which = 0 qkv, 1 o, 2 gate/up, 3 down, 4 LM head; *w_tiled = 0 row-major, 1 fragment-tiled bf16, 2 byte-tiled E4M3 (hwocr_gemm_skinny_w8).
+ * Only m's dimensions and the NULL-ness of the tiled weight pointers of m->L[0] / m->lm_head_t / m->lm_head8t are read.  Launches nothing. */
 int hwocr_decode_gemm_plan(const hwocr_decoder* m, int nseq, int which, int* N, int* K, int* epi, int* splitk, int* w_tiled);
 
 /* capture one decode step into a HIP graph; replay it n times back-to-back on `stream` */

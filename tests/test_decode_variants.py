@@ -15,9 +15,9 @@ PRESETS = ("qwen2-vl-2b", "qwen2.5-vl-7b", "qwen2.5-vl-3b", "paligemma-3b", "sma
 READS = (1, 3, 126, 252)
 
 
-def _gemm_variant(B, N, K, epi, splitk):
+def _gemm_variant(B, N, K, epi, splitk, w_tiled=1):
     buf = C.create_string_buffer(128)
-    _lib.check(_lib.hip().hwocr_gemm_skinny_variant(B, N, K, epi, splitk, 1, buf, len(buf)))
+    _lib.check(_lib.hip().hwocr_gemm_skinny_variant(B, N, K, epi, splitk, w_tiled, buf, len(buf)))
     return buf.value.decode()
 
 
@@ -54,6 +54,20 @@ def test_every_dispatched_decode_kernel_has_an_oracle_case(preset):
         if plan["attn"] not in attn:
             missing.append((reads, "attn", plan["attn"]))
     assert not missing, f"{preset}: decode kernels without a parity case: {missing}"
+
+
+@pytest.mark.parametrize("preset", ("paligemma-3b", "qwen2-vl-2b", "qwen2.5-vl-7b", "tinypg", "tiny"))
+def test_every_dispatched_e4m3_decode_kernel_has_an_oracle_case(preset):
+    """The same for engines built with fp8=True (E4M3 decode weights, hwocr_gemm_skinny_w8)."""
+    covered = {_gemm_variant(*c, w_tiled=2) for c in ops.DECODE_GEMM_CASES_W8}
+    cfg = engine.preset(preset)
+    missing = []
+    for reads in READS:
+        plan = engine.decode_plan(cfg, reads, fp8=True)
+        for name in engine.DECODE_GEMMS:
+            if plan[name][4] not in covered:
+                missing.append((reads, name) + plan[name])
+    assert not missing, f"{preset} (fp8): decode kernels without a parity case: {missing}"
 
 
 def test_bench_default_shapes_are_literal_cases():

@@ -956,6 +956,81 @@ def test_gemm_wide_fp8_gated(geglu):
     assert_close_bf16(out, want, ulps=3.0, atol=2e-3, what="gemm_wide_fp8 gated", mag=want.abs() * (1.0 + gate.abs()))
 
 
+# ---------------------------------------------------------------------------------------------- E4M3 decode GEMMs (weight-only fp8)
+def _tiled_fp8(wq):
+    n, k = wq.shape
+    out = torch.full((n * k,), 0x7F, dtype=torch.uint8, device=DEV)
+    assert lib().hwocr_tile_weights_fp8(p(wq), p(out), n, k, k, st()) == 0
+    sync()
+    return out
+
+
+def test_tile_weights_fp8_layout():
+    n, k = 48, 192
+    w = (torch.arange(n * k, dtype=torch.int64) % 251).to(torch.uint8).view(n, k).to(DEV)
+    t = _tiled_fp8(w).view(n // 16, k // 64, 4, 16, 2, 8).cpu()          # [tile][k tile][q][c][half][8]
+    want = w.cpu().view(n // 16, 16, k // 64, 2, 4, 8).permute(0, 2, 4, 1, 3, 5)   # [tile][kt][q][c][half][8]
+    assert torch.equal(t, want)
+
+
+# the decode GEMMs of the fp8 configuration exactly as hwocr_decode_step issues them: PaliGemma-3B (config 4), the Qwen2-VL-2B
+# shape under --fp8, the tiny golden model; (N, K, epi, splitk) from engine.decode_plan(..., fp8=True)
+DECODE_GEMM_SHAPES_W8 = {
+    3: [(2560, 2048, 5, 5), (32768, 2048, 7, 1), (2048, 16384, 5, 12), (257216, 2048, 0, 1), (17920, 1536, 4, 1), (512, 256, 0, 1)],
+    24: [(2560, 2048, 5, 5), (32768, 2048, 7, 1), (1024, 256, 7, 1)],
+    40: [(2048, 2048, 5, 5), (32768, 2048, 7, 1)],
+    126: [(2560, 2048, 5, 5), (2048, 2048, 5, 5), (32768, 2048, 7, 1), (2048, 16384, 5, 12), (257216, 2048, 0, 1), (17920, 1536, 4, 1)],
+    252: [(2560, 2048, 5, 4), (2048, 2048, 5, 4), (32768, 2048, 7, 1), (2048, 16384, 5, 8), (257216, 2048, 0, 1),
+          (2048, 1536, 5, 4), (17920, 1536, 4, 1), (1536, 8960, 5, 8), (151936, 1536, 0, 1), (37888, 3584, 4, 1),
+          (512, 256, 0, 1), (1024, 256, 7, 1), (256, 512, 5, 1), (512, 256, 4, 1)],
+}
+DECODE_GEMM_CASES_W8 = [(B,) + shape for B, shapes in DECODE_GEMM_SHAPES_W8.items() for shape in shapes]
+
+
+@pytest.mark.parametrize("B,N,K,epi,splitk", DECODE_GEMM_CASES_W8)
+def test_gemm_skinny_w8_decode_shapes(B, N, K, epi, splitk):
+    """hwocr_gemm_skinny_w8 = bf16 activations x E4M3 weight codes (one fp32 scale per output feature) against the exact product
+    of the SAME codes (oracle/fp8_ref.py decodes them): only the fp32 accumulation order and the bf16 epilogue separate the two."""
+    x = randbf(B, K, seed=80)
+    w = randbf(N, K, scale=K ** -0.5, seed=81)
+    wq, ws = _quant_gpu(w)
+    wt = _tiled_fp8(wq)
+    wdq = wq.view(torch.float8_e4m3fn).float()                           # the values the codes stand for
+    acc = (x.float() @ wdq.t()) * ws[None, :]
+    if epi == 5:
+        slabs = torch.full((splitk, B, N), float("nan"), dtype=torch.float32, device=DEV)
+        assert lib().hwocr_gemm_skinny_w8(p(x), p(wt), p(ws), None, p(slabs), B, N, K, K, N, 5, splitk, st()) == 0
+        sync()
+        got = slabs.sum(0)
+        assert torch.isfinite(got).all(), "a slab element was left unwritten"
+        assert torch.allclose(got, acc, rtol=1e-4, atol=2e-3), f"w8 partial splitk={splitk}: {(got - acc).abs().max()}"
+    elif epi == 0:
+        bias = randbf(N, scale=0.5, seed=82)
+        out = torch.full((B, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        assert lib().hwocr_gemm_skinny_w8(p(x), p(wt), p(ws), p(bias), p(out), B, N, K, K, N, 0, 1, st()) == 0
+        sync()
+        assert_close_bf16(out, acc + bias.float(), ulps=2.0, atol=2e-3, what="w8 linear")
+    else:
+        out = torch.full((B, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+        assert lib().hwocr_gemm_skinny_w8(p(x), p(wt), p(ws), None, p(out), B, N, K, K, N // 2, epi, 1, st()) == 0
+        sync()
+        want = _swiglu_ref(acc, geglu=(epi == 7))
+        gate = rbf(acc.view(B, N // 32, 2, 16)[:, :, 0, :]).reshape(B, N // 2)
+        assert_close_bf16(out, want, ulps=3.0, atol=2e-3, what=f"w8 glu epi={epi}", mag=want.abs() * (1.0 + gate.abs()))
+    # weight-only E4M3 stays within a few percent of the bf16 product's spread
+    exact = x.float() @ w.float().t()
+    assert float((acc - exact).abs().mean() / exact.abs().mean()) < 0.05
+
+
+def test_gemm_skinny_w8_rejects_bad_shapes():
+    z = torch.zeros(64, 64, dtype=torch.uint8, device=DEV)
+    f = torch.zeros(64, dtype=torch.float32, device=DEV)
+    x = randbf(4, 96)
+    assert lib().hwocr_gemm_skinny_w8(p(x), p(z), p(f), None, p(x), 4, 64, 96, 96, 64, 0, 1, st()) == 1     # K % 64
+    assert lib().hwocr_gemm_skinny_w8(p(x), p(z), None, None, p(x), 4, 64, 64, 64, 64, 0, 1, st()) == 1      # no scales
+    assert lib().hwocr_tile_weights_fp8(p(z), p(z), 40, 64, 64, st()) == 1                                  # N % 16
+
+
 def test_gemm_wide_fp8_rejects_bad_shapes():
     z = torch.zeros(256, 256, dtype=torch.uint8, device=DEV)
     s = torch.ones(256, dtype=torch.float32, device=DEV)
