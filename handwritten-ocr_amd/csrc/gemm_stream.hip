@@ -83,12 +83,11 @@ __device__ __forceinline__ void wait_dma(int pending) {  // leave `pending` of t
 // 8 E4M3 codes (two dwords) -> the bf16 fragment they stand for: every E4M3 value is exactly representable in bf16, so the
 // decode GEMMs of the fp8 configuration multiply exactly the stored codes (the per-feature scale goes into the epilogue).
 __device__ __forceinline__ bf16x8 e4m3x8_to_bf16(int lo, int hi) {
-  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
-  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
-  bf16x8 o;
-  o[0] = f2bf(a[0]); o[1] = f2bf(a[1]); o[2] = f2bf(b[0]); o[3] = f2bf(b[1]);
-  o[4] = f2bf(c[0]); o[5] = f2bf(c[1]); o[6] = f2bf(d[0]); o[7] = f2bf(d[1]);
-  return o;
+  // v_cvt_scalef32_pk_bf16_fp8 (gfx950): two codes -> two packed bf16 per instruction, scale 1 (4 instead of 8 conversions per
+  // fragment: the conversions are VALU work on the K-tile critical path of a kernel that is not weight-byte bound)
+  const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+  const bf16x2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+  return __builtin_shufflevector(__builtin_shufflevector(a, b, 0, 1, 2, 3), __builtin_shufflevector(c, d, 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // MT: 16-row activation tiles (Bsz <= 16 MT).  16 waves = MSPLIT (row halves) x 16/MSPLIT (tile groups): a wave multiplies

@@ -399,11 +399,14 @@ class ReadEngine:
     MAX_GRAPHS = 8  # captured decode graphs kept (one per distinct reads-in-flight / generation setting), least recently used out
 
     def __init__(self, cfg: ModelConfig, state_dict: dict, max_reads: int = 96, ctx: int = 2048, device: str | None = None,
-                 vit_batch: int = 8, prefill_batch: int = 16, attn_splits: int = 0, fp8: bool = False):
+                 vit_batch: int = 8, prefill_batch: int = 16, attn_splits: int = 0, fp8: bool = False,
+                 fp8_decode: bool | None = None):
         """device: None = the process's current device (one process per GPU: shard.init_from_env has already made
         LOCAL_RANK's device current).  fp8: run the wide GEMMs of the vision tower and of the decoder prefill (K a multiple
-        of 128) on E4M3 copies of the weights with per-token activation scales (BASELINE config 4); norms, attention, decode
-        steps stay bf16."""
+        of 128) on E4M3 copies of the weights with per-token activation scales (BASELINE config 4); norms and attention stay
+        bf16.  fp8_decode (with fp8; default: HWOCR_FP8_DECODE, off): the decode GEMMs and the LM head also read E4M3 weight codes
+        (hwocr_gemm_skinny_w8: half the weight bytes per step).  Exact, but measured SLOWER than the bf16 decode weights on this
+        part (PaliGemma-3B, 252 reads: 6.08 vs 5.86 ms per token — the decode GEMMs are not weight-byte bound), hence opt-in."""
         cfg.validate()
         if not torch.cuda.is_available():
             raise _lib.HwocrError("ReadEngine needs an MI355X (ROCm) device: there is no CPU path")
@@ -421,6 +424,7 @@ class ReadEngine:
         self.prefill_batch = prefill_batch
         self.attn_splits = attn_splits
         self.fp8 = bool(fp8)
+        self.fp8_decode = self.fp8 and (os.environ.get("HWOCR_FP8_DECODE", "0") not in ("", "0") if fp8_decode is None else bool(fp8_decode))
         self.collect_timings = False
         self.timings = {}
         self._keep = []  # everything the C structs point at
@@ -460,7 +464,7 @@ class ReadEngine:
     def _w8_tiled(self, pack: _lib.W8):
         """Byte-tiled copy of an E4M3 weight for the decode GEMMs (hwocr_tile_weights_fp8), or None."""
         q = getattr(pack, "codes", None)
-        if q is None or q.shape[0] % 16 or q.shape[1] % 64 or os.environ.get("HWOCR_FP8_DECODE", "1") == "0":  # (=0: A/B switch)
+        if q is None or q.shape[0] % 16 or q.shape[1] % 64 or not self.fp8_decode:
             return None
         n, k = q.shape
         out = torch.empty(n * k, dtype=torch.uint8, device=self.dev)
@@ -649,7 +653,7 @@ class ReadEngine:
                                 embed_scale=float(c.hidden) ** 0.5,
                                 embed=P(embed), lm_head=P(head), final_norm_w=P(self._t(sd[t + "norm.weight"])), L=layers,
                                 rope_cos=P(self.dec_cos), rope_sin=P(self.dec_sin), max_pos=int(ang.shape[0]))
-        head8 = self._w8(head)
+        head8 = self._w8(head) if self.fp8_decode else _lib.W8()
         head8t = self._w8_tiled(head8)
         if head8t is not None:
             self.dec.lm_head8t = _lib.W8(w=head8t, scale=head8.scale)

@@ -80,12 +80,15 @@ def test_graph_decode_equals_eager(eng):
 
 
 # ---------------------------------------------------------------------------------------------- E4M3 wide GEMMs (config 4)
-@pytest.fixture(scope="module")
-def eng8():
+# fp8_decode: the decode GEMMs and the LM head on E4M3 weight codes too (opt-in: exact but measured slower, engine.ReadEngine)
+@pytest.fixture(scope="module", params=[False, True], ids=["prefill_fp8", "prefill+decode_fp8"])
+def eng8(request):
     from handwritten_ocr_amd import engine
 
     sd = load_file(os.path.join(GOLD, "paligemma_tiny_weights.safetensors"))
-    e = engine.ReadEngine(engine.preset("tinypg"), sd, max_reads=8, ctx=256, vit_batch=2, prefill_batch=2, fp8=True)
+    e = engine.ReadEngine(engine.preset("tinypg"), sd, max_reads=8, ctx=256, vit_batch=2, prefill_batch=2, fp8=True,
+                          fp8_decode=request.param)
+    assert e.fp8_decode == request.param and bool(e.dec.lm_head8t.w) == request.param
     yield e
     e.close()
 
