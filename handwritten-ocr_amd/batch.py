@@ -294,6 +294,11 @@ def main(argv=None) -> None:
     transcribe_folder(images, out_dir, args.ground_truth_dir, params)
     if rank == 0:
         print(f"\nAll done. Results saved to {out_dir}")
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():  # ranks leave together (rank 0 is still writing while the others are done)
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -176,8 +176,10 @@ class Processor:
             if int((ids == c.image_token_id).sum()) != n_image_tokens:
                 raise ValueError("tokenizer.json does not keep the image placeholder as one token")
             return ids
-        if c.family == "paligemma":  # <image> x n, <bos>, prompt, newline (HF paligemma/processing_paligemma.py build_string_from_input)
-            return np.asarray([c.image_token_id] * n_image_tokens + [c.bos_id] + enc(prompt) + enc("\n"), dtype=np.int32)
+        if c.family == "paligemma":
+            # "<image>" x n + "<bos>" + prompt + "\n" tokenised as one string whose specials split it (HF
+            # paligemma/processing_paligemma.py build_string_from_input): the text part is encoded WITH its newline
+            return np.asarray([c.image_token_id] * n_image_tokens + [c.bos_id] + enc(prompt + "\n"), dtype=np.int32)
         ids = ([c.im_start_id] + enc("system\n" + SYSTEM_TEXT) + [c.im_end_id] + enc("\n")
                + [c.im_start_id] + enc("user\n") + [c.vision_start_id] + [c.image_token_id] * n_image_tokens
                + [c.vision_end_id] + enc(prompt) + [c.im_end_id] + enc("\n") + [c.im_start_id] + enc("assistant\n"))

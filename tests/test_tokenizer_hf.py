@@ -94,3 +94,17 @@ def test_template_runs_sandboxed(proc):
 def test_template_with_byte_tokenizer_is_refused(proc):
     with pytest.raises(ValueError):
         tokenizer.Processor(proc.cfg, tokenizer.ByteTokenizer(proc.cfg), template_dir=TOKDIR)
+
+
+def test_paligemma_prompt_ids_equal_hf_processor(kats):
+    """BASELINE config 4: PaliGemma's processor has no chat template; it builds "<image> x n <bos> prompt \\n".  The ids of
+    HF's own PaliGemmaProcessor (constructible offline) on tests/golden/tokenizer_pg_tiny/ against Processor.chat_ids."""
+    pg = kats["paligemma"]
+    cfg = engine.preset("tinypg")
+    cfg.image_token_id, cfg.bos_id, cfg.eos_ids, cfg.pad_id = pg["image_token_id"], pg["bos_token_id"], (pg["eos_token_id"],), pg["pad_token_id"]
+    p = tokenizer.Processor(cfg, tokenizer.HFTokenizer(cfg, os.path.join(GOLD, "tokenizer_pg_tiny")))
+    assert p.template is None
+    for c in pg["chat"]:
+        assert p.chat_ids(c["prompt"], c["image_tokens"]).tolist() == c["input_ids"]
+    for d in pg["decode"]:
+        assert p.decode(d["ids"], skip_special_tokens=True) == d["skip"]

@@ -644,10 +644,43 @@ def make_tokenizer() -> None:
     for seq in (cut, [ids["<|vision_start|>"]] + tok.encode("mid", add_special_tokens=False).ids + [ids["<|vision_end|>"]] + cut):
         dec.append({"ids": seq, "skip": proc.decode(seq, skip_special_tokens=True), "keep": proc.decode(seq, skip_special_tokens=False)})
     enc_kats = [{"text": t, "ids": fast(t)["input_ids"]} for t in texts + prompts + ["<|im_start|>user\n<|vision_start|><|image_pad|><|image_pad|><|vision_end|>x<|im_end|>\n"]]
+    # PaliGemma (BASELINE config 4): its processor has no chat template; it builds "<image> x n <bos> prompt \n"
+    # (processing_paligemma.py build_string_from_input).  HF's own PaliGemmaProcessor is constructible offline: run it.
+    from transformers.models.paligemma.processing_paligemma import PaliGemmaProcessor
+    from transformers.models.siglip import SiglipImageProcessorPil
+
+    ptok = Tokenizer(models.BPE())
+    ptok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    ptok.decoder = decoders.ByteLevel()
+    ptok.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=420, special_tokens=["<pad>", "<eos>", "<bos>"], show_progress=False,
+                                                         initial_alphabet=pre_tokenizers.ByteLevel.alphabet()))
+    pfast = PreTrainedTokenizerFast(tokenizer_object=ptok, bos_token="<bos>", eos_token="<eos>", pad_token="<pad>")
+    S = 56
+    pip_ = SiglipImageProcessorPil(size={"height": S, "width": S}, resample=3, do_rescale=True, do_normalize=True,
+                                   image_mean=[0.5] * 3, image_std=[0.5] * 3)
+    pip_.image_seq_length = (S // 14) ** 2
+    pproc = PaliGemmaProcessor(image_processor=pip_, tokenizer=pfast)   # adds "<image>" to the tokenizer
+    pg_dir = os.path.join(GOLD, "tokenizer_pg_tiny")
+    os.makedirs(pg_dir, exist_ok=True)
+    for fn in os.listdir(pg_dir):
+        os.remove(os.path.join(pg_dir, fn))
+    pproc.tokenizer.save_pretrained(pg_dir)
+    pg_cases = []
+    for i, prompt in enumerate(prompts):
+        img = Image.fromarray(make_page(10 + i, 80, 100), "RGB")
+        enc = pproc(text="<image>" + prompt, images=img, return_tensors="pt")
+        pg_cases.append({"prompt": prompt, "input_ids": enc["input_ids"][0].tolist(), "image_tokens": pip_.image_seq_length})
+    pg = {"image_token_id": pproc.image_token_id, "bos_token_id": pfast.bos_token_id, "eos_token_id": pfast.eos_token_id,
+          "pad_token_id": pfast.pad_token_id, "chat": pg_cases,
+          "decode": [{"ids": c["input_ids"][c["image_tokens"]:] + [pfast.eos_token_id],
+                      "skip": pproc.decode(c["input_ids"][c["image_tokens"]:] + [pfast.eos_token_id], skip_special_tokens=True)} for c in pg_cases]}
     with open(os.path.join(GOLD, "tokenizer_kats.json"), "w", encoding="utf-8") as f:
         json.dump({"source": "transformers PreTrainedTokenizerFast(tiny byte-level BPE).apply_chat_template(Qwen2-VL template) / __call__ / "
                              "decode + Qwen2VLImageProcessorPil grids; the <|image_pad|> expansion is Qwen2VLProcessor.replace_image_token restated",
-                   "special_ids": ids, "chat": cases, "decode": dec, "encode": enc_kats}, f, indent=0, ensure_ascii=True)
+                   "special_ids": ids, "chat": cases, "decode": dec, "encode": enc_kats,
+                   "paligemma": dict(pg, source="transformers PaliGemmaProcessor(SiglipImageProcessorPil, PreTrainedTokenizerFast(tiny "
+                                                "byte-level BPE)).__call__(text='<image>' + prompt, images=page) / .decode")},
+                  f, indent=0, ensure_ascii=True)
 
 
 def main() -> None:
