@@ -338,9 +338,32 @@ def spawn_ranks(n: int, argv: list[str]) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    # rank 0's stdout is read by a thread while every rank is watched: a rank that dies would leave the others waiting in a
+    # collective until the RCCL timeout, so the remaining ranks (these exact child processes) are terminated instead
+    import threading
+
+    chunks: list = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.5)
+    codes = []
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(p.wait())
+    reader.join(timeout=10)
+    out0 = chunks[0] if chunks else ""
+    lines = [] if failed else [l for l in (out0 or "").splitlines() if l.startswith("{")]
     if lines:
         print(lines[-1], flush=True)
     rc = next((c for c in codes if c), 0)
