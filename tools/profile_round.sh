@@ -20,4 +20,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write
     --no-cpu-baseline --no-extras "$@" > /dev/null 2>> $OUT/${TAG}_rocprof.err
 echo "write pass done"
 python3 $R/tools/pmc_summary.py /tmp/prof_fetch/*/*_counter_collection.csv /tmp/prof_write/*/*_counter_collection.csv $OUT/${TAG}_pmc_traffic.json
-rm -rf /tmp/prof_ks /tmp/prof_fetch /tmp/prof_write
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/prof_util -- python3 $R/bench.py --pages 12 --steps 1 --warmup 0 \
+    --new-tokens 4 --no-cpu-baseline --no-extras "$@" > /dev/null 2>> $OUT/${TAG}_rocprof.err
+python3 $R/tools/pmc_util.py /tmp/prof_util/*/*_counter_collection.csv > $OUT/${TAG}_pmc_util.txt
+cat $OUT/${TAG}_pmc_util.txt
+rm -rf /tmp/prof_ks /tmp/prof_fetch /tmp/prof_write /tmp/prof_util
