@@ -13,7 +13,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-HIP_SOURCES = ["gemm.hip", "gemm256.hip", "gemm_stream.hip", "attention.hip", "elementwise.hip", "imagepre.hip", "runtime.hip"]
+HIP_SOURCES = ["gemm.hip", "gemm256.hip", "gemm_stream.hip", "attention.hip", "attention_vit80x.hip", "elementwise.hip", "imagepre.hip",
+               "runtime.hip"]
+# attention_vit80x.hip: its score MFMAs must write arch VGPRs (the accumulator file is owned by its inline asm, see the file)
+EXTRA_FLAGS = {"attention_vit80x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 HIP_LIB = os.path.join(CSRC, "libhwocr_hip.so")
 TEXT_LIB = os.path.join(CSRC, "libhwocr_text.so")
 
@@ -41,7 +44,8 @@ def hipcc_path() -> str:
 
 def build_hip(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "hwocr.h")]
+    deps = srcs + [os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attention_args.h"),
+                   os.path.join(INCLUDE, "hwocr.h")]
     if not force and _newer(HIP_LIB, deps):
         return HIP_LIB
     objs = []
@@ -49,7 +53,7 @@ def build_hip(force: bool = False) -> str:
         o = s[:-4] + ".o"
         if force or not _newer(o, [s] + deps[len(srcs):]):
             _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
-                  "-I" + INCLUDE, "-c", s, "-o", o])
+                  *EXTRA_FLAGS.get(os.path.basename(s), []), "-I" + INCLUDE, "-c", s, "-o", o])
         objs.append(o)
     _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
     return HIP_LIB

@@ -11,31 +11,16 @@
 //  attn_decode  : one new token per read against its KV cache (HBM-bound).  K rows and V^T rows go
 //                 straight from HBM to MFMA operands; keys are split over waves and workgroups and merged
 //                 with the usual (m, l, O) rule.
+#include "attention_args.h"
 #include "common.h"
 #include "hwocr.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+
+using namespace hwocr_attn;
 
 namespace {
-
-constexpr float NEG_BIG = -1.0e30f;
-
-struct PrefillArgs {
-  const bf16* Q; const bf16* K; const bf16* VT; bf16* O; const int* lens;
-  long q_seg, q_head, q_row;
-  long k_seg, k_head, k_row;
-  long v_seg, v_head, v_row;
-  long o_seg, o_row;
-  int group;          // query heads per kv head
-  float scale_log2;   // softmax scale * log2(e)
-  int kv_tiled;       // K / V^T in the fragment-tiled cache layout (common.h) instead of rows
-  int heads, nseg, qblocks;  // 1-D grid decomposition (attn_vit80_kernel)
-  const int* seg_off;        // packed ragged segments (hwocr_attn_varlen): first row of every segment, multiple of 4
-  // Lazy running-max update of the two specialised kernels: the accumulators are rescaled only when some query's tile maximum
-  // exceeds its running reference by more than `slack` (log2 units); until then the weights are exp2(s - m_ref) <= 2^slack
-  // - still exact relative precision in bf16 / fp32 - and O / l is unchanged.  0 = rescale on every new maximum.
-  float slack = 0.f;
-};
 
 __device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -485,9 +470,6 @@ int launch_prefill(const PrefillArgs& a, int nseg, int heads, int max_len, hipSt
 //                     per tile less, and the running-max rescale covers it for free.
 //   * row max through v_max3 (fmaxf nests), exp2 of fma(score, scale, -max).
 // ------------------------------------------------------------------------------------------------
-constexpr int V80_K0 = 64 * 128, V80_K1 = 64 * 32, V80_VT = 88 * 128;
-constexpr int V80_STAGE = V80_K0 + V80_K1 + V80_VT;  // 21504 B
-
 // WAVES x 32 queries per workgroup.  Every workgroup streams the whole K / V^T of its (head, page) through LDS, so the
 // bytes entering the CUs per query fall with the queries per workgroup: at 4 waves (128 queries, 3 workgroups per CU) a
 // 12-page launch staged 13.5 GB in 1.8 ms = 7.5 TB/s, much of it from beyond L2 - the staging, not the matrix or vector pipes, was
@@ -691,12 +673,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void attn_vit80_ker
 }
 
 int launch_vit80(const PrefillArgs& a, int nseg, int heads, int max_len, hipStream_t st) {
-  // long segments (pages: 5184 tokens): 12 waves; short ones keep 128-query workgroups so the grid still fills the chip
-  static const int forced = [] { const char* e = getenv("HWOCR_VIT80_WAVES"); return e ? atoi(e) : 0; }();
-  const int waves = forced ? forced : (max_len >= 1536 ? 12 : 4);
+  // long segments (pages: 5184 tokens): the one-wave-per-SIMD kernel of attention_vit80x.hip (256 queries per workgroup); short ones
+  // keep 128-query workgroups so the grid still fills the chip.  HWOCR_VIT80_KERNEL = x | 12 | 4 forces a form (read per call, so a
+  // test can walk all three in one process): 12 = the 384-query / 12-wave form that x replaced (2.13-2.18 ms against 2.08-2.12 per
+  // 12-page launch; vision 2876-2937 -> 2837 ms per 84 pages in the bench).
+  const char* force = getenv("HWOCR_VIT80_KERNEL");
+  const bool wide = force ? force[0] == 'x' : max_len >= 1536;
+  const int waves = force && force[0] != 'x' ? (atoi(force) == 12 ? 12 : 4) : (max_len >= 1536 ? 12 : 4);
   PrefillArgs b = a;
   b.heads = heads;
   b.nseg = nseg;
+  if (wide) {
+    b.qblocks = (max_len + 255) / 256;
+    b.slack = attn_slack();
+    launch_vit80x(b, b.qblocks * heads * nseg, st);
+    return hwocr_launch_status();
+  }
   b.qblocks = (max_len + 32 * waves - 1) / (32 * waves);
   b.slack = attn_slack();
   if (waves == 12) {

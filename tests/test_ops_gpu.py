@@ -257,11 +257,15 @@ def test_attn_prefill(hd, Hq, Hkv, causal, tiled):
     assert torch.isfinite(out.float()).all()
 
 
-def test_attn_vit80_long_segments():
-    """Page-length segments take the 12-wave (384 queries per workgroup) form of the head_dim-80 kernel: ragged lengths
-    around its block size, one of them shorter than a single block."""
+@pytest.mark.parametrize("kernel", ["x", "12", "4"])
+@pytest.mark.parametrize("lens", [[2000, 1537, 383, 769], [2048, 64, 1, 1600], [255, 257, 1999, 130]])
+def test_attn_vit80_long_segments(kernel, lens, monkeypatch):
+    """Page-length segments take the one-wave-per-SIMD form of the head_dim-80 kernel (attention_vit80x.hip: 256 queries per
+    workgroup, output accumulators in asm-owned AGPRs); the 12-wave (384 queries) and 4-wave (128) forms stay selectable
+    (HWOCR_VIT80_KERNEL, read per call).  Ragged lengths around the block sizes, whole and partial last key tiles, segments of
+    one tile and of one token, K rows / V^T columns past each segment poisoned."""
+    monkeypatch.setenv("HWOCR_VIT80_KERNEL", kernel)
     hd, heads = 80, 2
-    lens = [2000, 1537, 383, 769]
     nseg, Lp = len(lens), 2048
     q = randbf(nseg, heads, Lp, hd, seed=41)
     k = randbf(nseg, heads, Lp, hd, seed=42)
@@ -280,7 +284,7 @@ def test_attn_vit80_long_segments():
     sync()
     for s_, n in enumerate(lens):
         want = _sdpa_ref(q[s_, :, :n].float(), k[s_, :, :n].float(), v[s_, :, :n].float(), False, scale)
-        assert_close_bf16(out[s_, :n].view(n, heads, hd), want, ulps=4.0, atol=4e-3, what=f"attn_vit80 12-wave seg {s_}")
+        assert_close_bf16(out[s_, :n].view(n, heads, hd), want, ulps=4.0, atol=4e-3, what=f"attn_vit80 kernel {kernel} seg {s_}")
     assert torch.isfinite(out.float()).all()
 
 

@@ -1,5 +1,5 @@
 """Time the ViT attention at the page shape of the bench (12 pages x 16 heads x 5184 tokens x head_dim 80, the tower's buffer
-layout).  HWOCR_ATTN_SLACK / HWOCR_VIT80_WAVES select the variant.  Run on the GPU box."""
+layout).  HWOCR_ATTN_SLACK / HWOCR_VIT80_KERNEL (x | 12 | 4) select the variant.  Run on the GPU box."""
 import os
 import sys
 
@@ -36,4 +36,4 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 fl = 4.0 * P * P * hd * heads * nimg
-print(f"HWOCR_ATTN_SLACK={os.environ.get('HWOCR_ATTN_SLACK', 'default')}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s  checksum {float(out.float().abs().mean()):.6f}")
+print(f"kernel={os.environ.get('HWOCR_VIT80_KERNEL', 'default')} slack={os.environ.get('HWOCR_ATTN_SLACK', 'default')}: {ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s  checksum {float(out.float().abs().mean()):.6f}")
