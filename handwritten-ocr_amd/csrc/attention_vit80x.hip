@@ -75,10 +75,17 @@ __device__ __forceinline__ f32x16 acc_read(int idx) {
 // left to three lockstep waves per SIMD (whose phases coincide: 17 % of SIMD cycles had both pipes busy):
 //   phase A(t): S(t+1) = K(t+1).Q^T   (20 MFMAs)  beside  the weights exp2(S(t)c - m) of tile t still to do (20 of 32 pairs)
 //   phase B(t): O += V^T(t).P(t)      (24 MFMAs)  beside  the row maximum of S(t+1), the new m / alpha, its first 12 pairs
-// one vector group per MFMA gap, kept in place by sched_barrier(0); every K / V^T fragment feeds two MFMAs (both query
-// blocks); K / V^T tiles arrive by LDS-DMA three tiles ahead into a 4-deep ring, one barrier per tile.  The running maximum
-// is per query (a lane's m moves only when its tile maximum exceeds it by more than `slack`); O is rescaled after phase B
-// when some lane's m moved.  LDS images and DMA plan as attn_vit80_kernel.
+// one MFMA then one vector group per gap, kept in place by sched_barrier(0); every K / V^T fragment feeds two MFMAs (both query
+// blocks) and is read two fragments ahead.  K / V^T tiles: register-staged (buffer loads in the gaps of phase A, ds_write in those
+// of phase B, two tiles ahead into a 4-deep ring of the LDS images of attn_vit80_kernel), one barrier per tile.  The running
+// maximum is per query (a lane's m moves only when its tile maximum exceeds it by more than `slack`); O is rescaled after phase B
+// when some lane's m moved.
+// Measured (12 pages x 16 heads x 5184 tokens, N(0,1) data, tools/bench_vit80x_stamps.py): 2785 cycles per 64-key tile at 1.88 GHz
+// = phase A 1240 + phase B 1235 + barrier 270 + glue 40; 2.07-2.12 ms per launch against 2.13-2.18 for the 12-wave form.  A lone
+// wave pays the SUM of its issue costs (MFMA 8, v_exp 8, other VALU 4, ds_read_b128 ~16, a 1-KiB buffer load ~60, an LDS-DMA
+// piece ~100 even against an empty descriptor): 1408 cycles of matrix time per tile sit under ~2500 of issue.  Two waves per SIMD
+// do not escape it: an 8-wave / 512-query form (query fragments re-read from LDS, <= 256 registers, waves 4..7 staggered by one
+// phase) measured 5470 cycles per PAIR of tiles = the same per tile, 2.18-2.26 ms, and was dropped.
 // ------------------------------------------------------------------------------------------------
 constexpr int V80X_STAGES = 4;
 
@@ -260,6 +267,9 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
         } else {
           Sn[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f % 3], qf[qb][s], Sn[qb][kb], 0, 0, 0);
         }
+        // the MFMA leads its gap: left free, hipcc hoists a gap's vector work above its MFMA, two MFMAs end up adjacent and the
+        // second one holds the (in-order) wave at issue for the 32 cycles of the first with no vector instruction going out
+        __builtin_amdgcn_sched_barrier(0);
         if (weights) {
           weigh(Sc, Pc, 12 + 2 * f + qb);
           const int gap = 2 * f + qb;  // tile t + 2 is requested in gaps 2, 6, 10, 14, 18 ...
@@ -285,6 +295,7 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         acc_mfma(3 * qb + d, vf[f % 3], Pc[qb][c >> 1][c & 1]);  // same accumulator again 6 gaps later
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (next) {
           const int gap = 2 * f + qb;
           if (gap < 10) {  // 38 chain steps over 10 gaps, the two query blocks alternating
@@ -417,6 +428,7 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
     }
   }
 }
+
 
 }  // namespace
 
