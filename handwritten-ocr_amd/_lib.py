@@ -10,7 +10,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 7  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
+ABI_VERSION = 8  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
 
 P = C.c_void_p
 I = C.c_int
@@ -102,7 +102,7 @@ class DecWs(C.Structure):
 class GenState(C.Structure):
     _fields_ = [(n, P) for n in ("cur_ids", "lens", "n_gen", "finished", "out_tokens", "rope_delta")] + [
         ("max_new", I), ("min_new", I), ("n_eos", I), ("pad_id", I), ("eos", I * 4), ("seen", P), ("seen_ld", I),
-        ("rep_penalty", F), ("status", P)]
+        ("rep_penalty", F), ("status", P), ("do_sample", I), ("temperature", F), ("top_k", I), ("top_p", F), ("seed", C.c_ulonglong), ("read_ids", P)]
 
 
 _HIP_SIGS = {
@@ -133,6 +133,7 @@ _HIP_SIGS = {
     "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, I, I, I, I, P, P], I),
     "hwocr_embed_splice": ([P, P, P, P, P, I, I, F, P], I),
     "hwocr_argmax_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P, I, F, P], I),
+    "hwocr_sample_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P, I, F, F, I, F, C.c_ulonglong, P, P, P], I),
     "hwocr_vit_forward": ([C.POINTER(Vit), C.POINTER(VitWs), P, I, I, I, I, C.POINTER(VitLayout), P, P], I),
     "hwocr_prefill": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), P, P, P, P, P, P,
                        I, I, I, I, P], I),

@@ -601,6 +601,314 @@ __global__ __launch_bounds__(ARG_THREADS) void argmax_advance_kernel(SelectArgs 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Token draw of generate(do_sample=True): temperature -> top-k -> top-p -> multinomial (HF generation/logits_process.py warpers +
+// generation/utils.py _sample), as the exact integer procedure "hwocr sampling v1" that oracle/sampling.py spells out: distance keys
+// q = floor((max - score) * 65536) (clamped), fixed-point weights floor(2^32 * 2^(-d * log2e / T)) from a non-fused fp32 polynomial,
+// radix selection of the top-k / nucleus thresholds over (count | mass) histograms, Philox4x32-10 keyed by (seed; read, step), inverse
+// CDF in token-id order.  Integer sums and a counter-based RNG: a read's tokens depend on (seed, read index, step) only.
+// One workgroup per read; the row (<= 500 KB of bf16 logits) is walked ~6 times out of L2.
+// ------------------------------------------------------------------------------------------------
+struct SampleArgs {
+  SelectArgs g;
+  float c;        // log2(e) / temperature, fp32
+  int top_k;      // <= 0 or >= V: off
+  float top_p;    // >= 1: off
+  unsigned seed_lo, seed_hi;
+  const int* read_ids;  // the caller's number of each read (RNG counter), or nullptr: the row index
+  unsigned long long* dbg;  // optional [nseq][8]: M bits, top-k key, W, P, nucleus key, kept mass, target, token
+};
+constexpr int SMP_QMAX = (1 << 22) - 1;
+constexpr int SMP_BINS = 2048;
+
+__device__ __forceinline__ unsigned long long smp_weight(float d, float c) {
+  const float y = -__fmul_rn(d, c);
+  if (!(y > -40.0f)) return 0ull;
+  const float n = __builtin_rintf(y);
+  const float f = __fsub_rn(y, n);
+  float r = 0.00015403530393381608f;
+  r = __fadd_rn(__fmul_rn(r, f), 0.0013333558146428443f);
+  r = __fadd_rn(__fmul_rn(r, f), 0.009618129107628477f);
+  r = __fadd_rn(__fmul_rn(r, f), 0.05550410866482158f);
+  r = __fadd_rn(__fmul_rn(r, f), 0.2402265069591007f);
+  r = __fadd_rn(__fmul_rn(r, f), 0.6931471805599453f);
+  r = __fadd_rn(__fmul_rn(r, f), 1.0f);
+  return (unsigned long long)__builtin_ldexp((double)r, (int)n + 32);
+}
+__device__ __forceinline__ int smp_key(float d) {
+  const float t = __builtin_floorf(__fmul_rn(d, 65536.0f));
+  return (t >= (float)SMP_QMAX || !(t == t) || __builtin_isinf(t)) ? SMP_QMAX : (int)t;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+  const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long u = shfl_u64(v, max(lane - o, 0));
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(ARG_THREADS) void sample_advance_kernel(SampleArgs a) {
+  constexpr int NW = ARG_THREADS / 64;
+  __shared__ unsigned long long s_hist[SMP_BINS];
+  __shared__ unsigned long long s_wave[NW];
+  __shared__ float s_fmax[NW];
+  __shared__ unsigned long long s_res[2];  // crossing bin, mass before it
+  __shared__ int s_tok;
+  const SelectArgs& g = a.g;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bf16* row = g.logits + (long)b * g.ldl;
+  const bool suppress = g.n_gen[b] < g.min_new;
+  const int nch = g.V / 8;
+  if (g.seen) {  // the token that produced these logits joins the repetition bitmap first (as argmax_advance_kernel)
+    if (tid == 0 && g.n_gen[b] > 0 && !g.finished[b]) {
+      const int t = g.cur_ids[b];
+      if (t >= 0 && t < g.V) g.seen[(long)b * g.seen_ld + (t >> 5)] |= 1u << (t & 31);
+    }
+    __syncthreads();
+  }
+  const unsigned* seen = g.seen ? g.seen + (long)b * g.seen_ld : nullptr;
+  // the 8 fp32 scores of chunk ch (ids 8 ch .. 8 ch + 7): repetition penalty, EOS suppression - exactly the greedy path's
+  auto scores = [&](int ch, float (&x)[8]) {
+    const bf16x8 v = *(const bf16x8*)(row + (long)ch * 8);
+    const unsigned bits = seen ? (seen[ch >> 2] >> ((ch & 3) * 8)) & 0xffu : 0u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = bf2f(v[e]);
+      if ((bits >> e) & 1u) s = s < 0.f ? s * g.rep_penalty : s / g.rep_penalty;
+      if (suppress)
+        for (int k = 0; k < g.n_eos; ++k)
+          if (ch * 8 + e == g.eos[k]) s = -INFINITY;
+      x[e] = s;
+    }
+  };
+  // ---- the maximum
+  float mx = -INFINITY;
+  for (int ch = tid; ch < nch; ch += ARG_THREADS) {
+    float x[8];
+    scores(ch, x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, x[e]);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) s_fmax[w] = mx;
+  __syncthreads();
+  float M = s_fmax[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) M = fmaxf(M, s_fmax[k]);
+
+  // first bin (ascending key order = descending score) at which the running sum of s_hist reaches `need`; all bins if it never does
+  auto crossing = [&](unsigned long long need, unsigned long long& before, unsigned long long& total) -> int {
+    const unsigned long long h0 = s_hist[2 * tid], h1 = s_hist[2 * tid + 1];
+    const unsigned long long incl = wave_incl_scan_u64(h0 + h1, lane);
+    if (lane == 63) s_wave[w] = incl;
+    if (tid == 0) { s_res[0] = SMP_BINS - 1; s_res[1] = ~0ull; }
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      if (k < w) base += s_wave[k];
+      tot += s_wave[k];
+    }
+    const unsigned long long excl = base + incl - (h0 + h1);
+    if (excl < need && need <= excl + h0 + h1) {  // exactly one thread
+      const bool first = need <= excl + h0;
+      s_res[0] = 2 * tid + (first ? 0 : 1);
+      s_res[1] = first ? excl : excl + h0;
+    }
+    __syncthreads();
+    const int bin = (int)s_res[0];
+    before = s_res[1] == ~0ull ? 0 : s_res[1];  // (never reached: keep everything; `before` is then unused)
+    total = tot;
+    __syncthreads();
+    return bin;
+  };
+  auto clear_hist = [&]() {
+    s_hist[2 * tid] = 0;
+    s_hist[2 * tid + 1] = 0;
+    __syncthreads();
+  };
+
+  // ---- top-k: the k-th smallest key by two 11-bit levels of counting
+  int tk = SMP_QMAX;
+  if (a.top_k > 0 && a.top_k < g.V) {
+    unsigned long long before, total;
+    clear_hist();
+    unsigned far = 0;  // keys at the clamp (masked / very distant scores) are counted in a register: one hot bin otherwise
+    for (int ch = tid; ch < nch; ch += ARG_THREADS) {
+      float x[8];
+      scores(ch, x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int q = smp_key(__fsub_rn(M, x[e]));
+        if (q == SMP_QMAX) ++far;
+        else atomicAdd(&s_hist[q >> 11], 1ull);
+      }
+    }
+    if (far) atomicAdd(&s_hist[SMP_BINS - 1], (unsigned long long)far);
+    __syncthreads();
+    const int b1 = crossing((unsigned long long)a.top_k, before, total);
+    const unsigned long long need2 = (unsigned long long)a.top_k - before;
+    clear_hist();
+    for (int ch = tid; ch < nch; ch += ARG_THREADS) {
+      float x[8];
+      scores(ch, x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int q = smp_key(__fsub_rn(M, x[e]));
+        if ((q >> 11) == b1) atomicAdd(&s_hist[q & 2047], 1ull);
+      }
+    }
+    __syncthreads();
+    const int b2 = crossing(need2, before, total);
+    tk = (b1 << 11) | b2;
+  }
+  // ---- top-p: the key at which the mass from the top reaches P = top_p * W
+  int tau = SMP_QMAX;
+  unsigned long long W = 0, P = 0;
+  if (a.top_p < 1.0f) {
+    unsigned long long before, total;
+    clear_hist();
+    for (int ch = tid; ch < nch; ch += ARG_THREADS) {
+      float x[8];
+      scores(ch, x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = __fsub_rn(M, x[e]);
+        const int q = smp_key(d);
+        if (q <= tk) {
+          const unsigned long long wt = smp_weight(d, a.c);
+          if (wt) atomicAdd(&s_hist[q >> 11], wt);
+        }
+      }
+    }
+    __syncthreads();
+    (void)crossing(~0ull - 1, before, W);  // W = the total (the crossing itself is not reached)
+    const double pw = __builtin_floor((double)a.top_p * (double)W);
+    P = pw < 1.0 ? 1ull : (unsigned long long)pw;
+    const int b1 = crossing(P, before, total);
+    const unsigned long long need2 = P - before;
+    clear_hist();
+    for (int ch = tid; ch < nch; ch += ARG_THREADS) {
+      float x[8];
+      scores(ch, x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = __fsub_rn(M, x[e]);
+        const int q = smp_key(d);
+        if (q <= tk && (q >> 11) == b1) {
+          const unsigned long long wt = smp_weight(d, a.c);
+          if (wt) atomicAdd(&s_hist[q & 2047], wt);
+        }
+      }
+    }
+    __syncthreads();
+    const int b2 = crossing(need2, before, total);
+    tau = (b1 << 11) | b2;
+  }
+  const int qlim = min(tk, tau);
+  // ---- the draw: kept mass per wave over contiguous id ranges, then the wave that holds the target walks its range again
+  const int cpw = (nch + NW - 1) / NW;  // chunks per wave
+  const int c0 = w * cpw, c1 = min(nch, c0 + cpw);
+  auto chunk_mass = [&](int ch, unsigned long long (&wt)[8]) -> unsigned long long {
+    float x[8];
+    scores(ch, x);
+    unsigned long long sum = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = __fsub_rn(M, x[e]);
+      wt[e] = smp_key(d) <= qlim ? smp_weight(d, a.c) : 0ull;
+      sum += wt[e];
+    }
+    return sum;
+  };
+  unsigned long long mine = 0;
+  for (int ch = c0 + lane; ch < c1; ch += 64) {
+    unsigned long long wt[8];
+    mine += chunk_mass(ch, wt);
+  }
+  mine = wave_incl_scan_u64(mine, lane);
+  if (lane == 63) s_wave[w] = mine;
+  if (tid == 0) s_tok = -1;
+  __syncthreads();
+  unsigned long long Wk = 0, wbase = 0;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    if (k < w) wbase += s_wave[k];
+    Wk += s_wave[k];
+  }
+  unsigned ctr[4] = {(unsigned)(a.read_ids ? a.read_ids[b] : b), (unsigned)g.n_gen[b], 0u, 0u};
+  philox4x32_10(ctr, a.seed_lo, a.seed_hi);
+  const unsigned long long r64 = ((unsigned long long)ctr[1] << 32) | ctr[0];
+  const unsigned long long target = __umul64hi(Wk, r64);
+  if (wbase <= target && target < wbase + s_wave[w]) {  // this wave's id range holds the target (wave-uniform)
+    unsigned long long run = wbase;
+    for (int cb = c0; cb < c1; cb += 64) {
+      const int ch = cb + lane;
+      unsigned long long wt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const unsigned long long m = ch < c1 ? chunk_mass(ch, wt) : 0ull;
+      const unsigned long long incl = wave_incl_scan_u64(m, lane);
+      const unsigned long long trip = shfl_u64(incl, 63);
+      if (run + trip > target) {
+        const unsigned long long hit = __ballot(run + incl > target);
+        const int first = __ffsll((long long)hit) - 1;
+        if (lane == first) {
+          unsigned long long acc = run + incl - m;
+          int tok = ch * 8 + 7;
+          for (int e = 0; e < 8; ++e) {
+            acc += wt[e];
+            if (acc > target) { tok = ch * 8 + e; break; }
+          }
+          s_tok = tok;
+        }
+        break;
+      }
+      run += trip;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int tok = s_tok;
+    if (a.dbg) {
+      unsigned long long* o = a.dbg + (long)b * 8;
+      o[0] = (unsigned long long)__float_as_uint(M);
+      o[1] = (unsigned long long)tk;
+      o[2] = W;
+      o[3] = P;
+      o[4] = (unsigned long long)tau;
+      o[5] = Wk;
+      o[6] = target;
+      o[7] = (unsigned long long)(long long)tok;
+    }
+    if (g.finished[b]) {
+      tok = g.pad_id;
+    } else {
+      for (int k = 0; k < g.n_eos; ++k)
+        if (tok == g.eos[k]) g.finished[b] = 1;
+    }
+    const int n = g.n_gen[b];
+    if (n < g.max_new) g.out_tokens[(long)b * g.max_new + n] = tok;
+    g.n_gen[b] = n + 1;
+    g.cur_ids[b] = tok;
+    g.lens[b] += 1;
+  }
+}
+
 }  // namespace
 
 extern "C" int hwocr_patchify(const void* img, const void* lut, void* out, int nimg, int H, int W, int patch,
@@ -767,5 +1075,22 @@ extern "C" int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq
                {0, 0, 0, 0}, n_eos, pad_id, (seen && rep_penalty != 1.0f) ? seen : nullptr, seen_ld, rep_penalty};
   for (int k = 0; k < n_eos; ++k) a.eos[k] = eos[k];
   hipLaunchKernelGGL(argmax_advance_kernel, dim3(nseq), dim3(ARG_THREADS), 0, stream, a);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_sample_advance(const void* logits, int ldl, int V, int nseq, int* cur_ids, int* lens, int* n_gen,
+                                    int* finished, int* out_tokens, int max_new, int min_new, const int* eos, int n_eos,
+                                    int pad_id, unsigned* seen, int seen_ld, float rep_penalty, float temperature, int top_k,
+                                    float top_p, unsigned long long seed, const int* read_ids, unsigned long long* debug,
+                                    hipStream_t stream) {
+  (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
+  if (nseq <= 0 || V % 8 || ldl % 8 || n_eos < 0 || n_eos > 4) return HWOCR_EINVAL;
+  if (seen && (seen_ld * 32 < V || !(rep_penalty > 0.f))) return HWOCR_EINVAL;
+  if (!(temperature > 0.f) || !(top_p > 0.f)) return HWOCR_EINVAL;
+  SampleArgs a{{(const bf16*)logits, ldl, V, cur_ids, lens, n_gen, finished, out_tokens, max_new, min_new,
+                {0, 0, 0, 0}, n_eos, pad_id, (seen && rep_penalty != 1.0f) ? seen : nullptr, seen_ld, rep_penalty},
+               1.4426950408889634f / temperature, top_k, top_p, (unsigned)seed, (unsigned)(seed >> 32), read_ids, debug};
+  for (int k = 0; k < n_eos; ++k) a.g.eos[k] = eos[k];
+  hipLaunchKernelGGL(sample_advance_kernel, dim3(nseq), dim3(ARG_THREADS), 0, stream, a);
   return hwocr_launch_status();
 }

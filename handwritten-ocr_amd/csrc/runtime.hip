@@ -222,6 +222,14 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
                           m->eps, G, st));
   CHECK(decode_gemm(ws->hn, m->lm_head, m->lm_head_t, m->lm_head8t.w, m->lm_head8t.scale, ws->logits, nseq, m->vocab, Hd, m->vocab,
                     HWOCR_EPI_LINEAR, 1, st));  // the same LM head (bf16 or E4M3) as every later step
+  if (gs->do_sample) {
+    if (!gs->read_ids) return HWOCR_EINVAL;  // (a chunk's rows would otherwise be numbered from 0: not the decode step's numbers)
+    CHECK(hwocr_sample_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids + seq0, gs->lens + seq0, gs->n_gen + seq0,
+                               gs->finished + seq0, gs->out_tokens + (long)seq0 * gs->max_new, gs->max_new, gs->min_new, gs->eos,
+                               gs->n_eos, gs->pad_id, gs->seen ? gs->seen + (long)seq0 * gs->seen_ld : nullptr, gs->seen_ld,
+                               gs->rep_penalty, gs->temperature, gs->top_k, gs->top_p, gs->seed, gs->read_ids + seq0, nullptr, st));
+    return HWOCR_OK;
+  }
   CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids + seq0, gs->lens + seq0,
                              gs->n_gen + seq0, gs->finished + seq0, gs->out_tokens + (long)seq0 * gs->max_new,
                              gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id,
@@ -309,6 +317,13 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   }
   CHECK(decode_gemm(ws->hn, m->lm_head, m->lm_head_t, m->lm_head8t.w, m->lm_head8t.scale, ws->logits, nseq, m->vocab, Hd, m->vocab,
                     HWOCR_EPI_LINEAR, 1, st));
+  if (gs->do_sample) {
+    if (!gs->read_ids) return HWOCR_EINVAL;
+    CHECK(hwocr_sample_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished, gs->out_tokens,
+                               gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, gs->seen, gs->seen_ld, gs->rep_penalty,
+                               gs->temperature, gs->top_k, gs->top_p, gs->seed, gs->read_ids, nullptr, st));
+    return HWOCR_OK;
+  }
   CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished,
                              gs->out_tokens, gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, gs->seen, gs->seen_ld,
                              gs->rep_penalty, st));

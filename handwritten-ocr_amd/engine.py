@@ -71,7 +71,11 @@ class ModelConfig:
     # generation defaults of the checkpoint (generation_config.json): only the deterministic part is implemented — the
     # repetition penalty; temperatures of the Qwen-VL checkpoints (1e-6 .. 0.01 with top_k 1) make sampling the argmax
     repetition_penalty: float = 1.0
-    sampling_note: str = ""  # what generation_config.json asked for beyond greedy (see _apply_generation_config)
+    sampling_note: str = ""  # what generation_config.json said about sampling (see _apply_generation_config)
+    do_sample: bool = False  # generate(do_sample=True): hwocr_sample_advance ("hwocr sampling v1": DESIGN.md §2, oracle/sampling.py)
+    temperature: float = 1.0
+    top_k: int = 0           # 0 = off
+    top_p: float = 1.0       # 1 = off
     # processor bounds (ocr_agent/config.py:17-18)
     min_pixels: int = 256 * 256
     max_pixels: int = 1024 * 1024
@@ -258,11 +262,12 @@ def normalize_keys(sd: dict) -> dict:
 
 def _apply_generation_config(cfg: ModelConfig, path: str) -> None:
     """generation_config.json of the checkpoint = the defaults `model.generate(**inputs, max_new_tokens=...)` runs with in the
-    reference (tools.py:765 passes nothing else).  Honoured: eos_token_id (int or list), pad_token_id, repetition_penalty.
-    NOT built: multinomial sampling — HF draws with torch.multinomial from torch's RNG stream (generation/utils.py:2919-2925),
-    which no other implementation reproduces token for token; this engine always takes the argmax (HF do_sample=False).  That is
-    exact for top_k == 1 and indistinguishable for the near-zero temperatures the Qwen-VL / olmOCR checkpoints ship; for anything
-    else the divergence is recorded in cfg.sampling_note and printed once at load time."""
+    reference (tools.py:765 passes nothing else).  Honoured: eos_token_id (int or list), pad_token_id, repetition_penalty,
+    do_sample with temperature / top_k / top_p (HF's defaults 1.0 / 50 / 1.0 where the file is silent).  HF draws with
+    torch.multinomial from torch's RNG stream (generation/utils.py:2919-2925), which no other implementation reproduces token for
+    token: the draw here keeps HF's distribution but comes from a counter-based RNG keyed by (seed, read, step)
+    (hwocr_sample_advance; seed = ReadEngine.seed / HWOCR_SAMPLE_SEED).  top_k == 1 is the argmax whatever the RNG says and stays on the
+    greedy path (what the Qwen2-VL checkpoints ship)."""
     gen_path = os.path.join(path, "generation_config.json")
     if not os.path.exists(gen_path):
         return
@@ -278,13 +283,18 @@ def _apply_generation_config(cfg: ModelConfig, path: str) -> None:
     if g.get("pad_token_id") is not None:
         cfg.pad_id = int(g["pad_token_id"])
     if g.get("do_sample"):
-        t, k, p = g.get("temperature", 1.0), g.get("top_k", 50), g.get("top_p", 1.0)
-        if k == 1 or (t is not None and t <= 0.05):
-            cfg.sampling_note = f"do_sample with temperature {t}, top_k {k}: selects the argmax (greedy here is the same choice)"
+        t = g.get("temperature")
+        k = g.get("top_k")
+        p = g.get("top_p")
+        t, k, p = (1.0 if t is None else float(t)), (50 if k is None else int(k)), (1.0 if p is None else float(p))
+        if k == 1:
+            cfg.sampling_note = f"do_sample with top_k 1 (temperature {t}, top_p {p}): the argmax - greedy path"
         else:
-            cfg.sampling_note = (f"checkpoint asks for sampling (temperature {t}, top_k {k}, top_p {p}); multinomial sampling is not "
-                                 "built: reads are greedy (HF do_sample=False), i.e. NOT what the reference would draw")
-            print(f"  [ocr] warning: {cfg.sampling_note}")
+            if not t > 0 or not p > 0:
+                raise ValueError(f"generation_config.json: temperature {t} / top_p {p} must be positive")
+            cfg.do_sample, cfg.temperature, cfg.top_k, cfg.top_p = True, t, k, p
+            cfg.sampling_note = (f"do_sample: temperature {t}, top_k {k}, top_p {p} - drawn by hwocr_sample_advance (HF's distribution, "
+                                 "own counter-based RNG: not HF's token stream)")
 
 
 def load_checkpoint_dir(path: str, device="cuda") -> tuple[ModelConfig, dict]:
@@ -427,6 +437,7 @@ class ReadEngine:
         self.fp8_decode = self.fp8 and (os.environ.get("HWOCR_FP8_DECODE", "0") not in ("", "0") if fp8_decode is None else bool(fp8_decode))
         self.collect_timings = False
         self.timings = {}
+        self.seed = int(os.environ.get("HWOCR_SAMPLE_SEED", "0")) & (2 ** 64 - 1)  # key of the sampling RNG (cfg.do_sample reads only)
         self._keep = []  # everything the C structs point at
         self._tiled_keep = []
         self._graphs = {}
@@ -681,6 +692,7 @@ class ReadEngine:
         self.finished = torch.zeros(R, **i32)
         self.rope_delta = torch.zeros(R, **i32)
         self.status = torch.zeros(1, **i32)  # HWOCR_STATUS_* bits raised on the device (hwocr_gen_state.status)
+        self.read_ids = torch.arange(R, **i32)  # the caller's number of the read in each slot (sampling RNG counter)
         self.out_tokens = None
         self._seen = None
         self._tok_bufs = {}
@@ -838,10 +850,30 @@ class ReadEngine:
         return emb, grids, tok_rows
 
     # ------------------------------------------------------------------------------------------ generate
+    def _sampling(self, sample: dict | None) -> tuple:
+        """(do_sample, temperature, top_k, top_p, seed) of a call: the checkpoint's generation_config unless `sample` overrides it."""
+        c = self.cfg
+        if sample is None:
+            if not c.do_sample:
+                return (0, 1.0, 0, 1.0, 0)
+            t, k, p, seed = c.temperature, c.top_k, c.top_p, self.seed
+        elif not sample:
+            return (0, 1.0, 0, 1.0, 0)
+        else:
+            t, k, p = float(sample.get("temperature", 1.0)), int(sample.get("top_k", 0)), float(sample.get("top_p", 1.0))
+            seed = int(sample.get("seed", self.seed)) & (2 ** 64 - 1)
+        if not t > 0 or not p > 0:
+            raise ValueError(f"sampling needs temperature > 0 and top_p > 0 (got {t}, {p})")
+        if k == 1:
+            return (0, 1.0, 0, 1.0, 0)  # the argmax, whatever is drawn
+        return (1, t, k if 0 < k < c.vocab else 0, min(p, 1.0), seed)
+
     def generate(self, pages: list[np.ndarray], prompts: list[np.ndarray], max_new: int, min_new: int = 0,
                  forced: np.ndarray | None = None, return_logits: bool = False, use_graph: bool = True,
-                 repetition_penalty: float | None = None):
-        """Greedy reads.  pages[i]: uint8 [H, W, 3] at tower resolution; prompts[i]: int32 token ids containing one run
+                 repetition_penalty: float | None = None, sample: dict | None = None, read_base: int = 0):
+        """Reads: greedy, or drawn (cfg.do_sample from generation_config.json, or `sample` = dict(temperature, top_k, top_p[, seed])
+        for this call; `sample={}` forces greedy): read i draws from the RNG stream of read number read_base + i, whichever slot or
+        batch it is decoded in.  pages[i]: uint8 [H, W, 3] at tower resolution; prompts[i]: int32 token ids containing one run
         of image placeholders sized for pages[i].  Returns list of generated-token lists (and, for tests, the per-step
         logits of every read when return_logits; `forced` [R][max_new] teacher-forces the fed tokens)."""
         c, lib, dev = self.cfg, self.lib, self.dev
@@ -909,12 +941,16 @@ class ReadEngine:
                 bits[r, np.asarray(prompts[r], np.int64)] = 1
             words = np.packbits(bits, axis=1, bitorder="little").view(np.uint32).astype(np.int64).astype(np.int32, casting="unsafe")
             self._seen[:R].copy_(torch.from_numpy(words.reshape(R, seen_ld)).to(dev))
+        smp = self._sampling(sample)
+        if smp[0]:
+            self.read_ids[:R].copy_(torch.arange(read_base, read_base + R, dtype=torch.int32))
         gs = _lib.GenState(cur_ids=_lib.ptr(self.cur_ids), lens=_lib.ptr(self.lens), n_gen=_lib.ptr(self.n_gen),
                            finished=_lib.ptr(self.finished), out_tokens=_lib.ptr(self.out_tokens),
                            rope_delta=_lib.ptr(self.rope_delta), max_new=max_new, min_new=min_new,
                            n_eos=min(len(c.eos_ids), 4), pad_id=c.pad_id, eos=eos,
                            seen=_lib.ptr(self._seen) if rp != 1.0 else None, seen_ld=seen_ld, rep_penalty=rp,
-                           status=_lib.ptr(self.status))
+                           status=_lib.ptr(self.status), do_sample=smp[0], temperature=smp[1], top_k=smp[2], top_p=smp[3],
+                           seed=smp[4], read_ids=_lib.ptr(self.read_ids))
         pb = min(self.prefill_batch, R)
         ws = self._dec_ws(max(pb * Tp, self.max_reads))
         step_logits = [] if return_logits else None
@@ -942,7 +978,7 @@ class ReadEngine:
         splits = self.attn_splits or pick_attn_splits(R, c.kv_heads)
         steps = max_new - 1
         if use_graph and not return_logits and forced is None and steps > 0:
-            key = (R, splits, max_new, min_new, rp, tuple(c.eos_ids), c.pad_id)
+            key = (R, splits, max_new, min_new, rp, tuple(c.eos_ids), c.pad_id, smp)  # everything the captured launches carry by value
             if key not in self._graphs:
                 # one eager step first: lazy one-time kernel attributes must not be set inside a capture
                 _lib.check(lib.hwocr_decode_step(C.byref(self.dec), C.byref(ws), C.byref(self.kv), C.byref(gs), R, splits, st))
@@ -991,8 +1027,8 @@ class ReadEngine:
 
     # ------------------------------------------------------------------------------------------ continuous batching
     def generate_stream(self, pages: list, prompts: list, max_new: int, min_new: int = 0, sync_every: int = 16,
-                        repetition_penalty: float | None = None, min_admit: int = 0) -> list[list[int]]:
-        """Greedy reads of ANY number of (page, prompt) pairs through the engine's `max_reads` decode slots, refilled as
+                        repetition_penalty: float | None = None, min_admit: int = 0, sample: dict | None = None) -> list[list[int]]:
+        """Reads (greedy or drawn, as `generate`; read i draws from the RNG stream of read number i) of ANY number of (page, prompt) pairs through the engine's `max_reads` decode slots, refilled as
         reads finish (EOS or max_new): the lockstep `generate` keeps a whole batch decoding until its longest read is done,
         which with the reference's 2048-token budget (config.py:19) and pages of a few hundred tokens idles most slots.
         Every `sync_every` decode steps the host looks at the stop flags, harvests finished reads, and prefills new ones
@@ -1016,12 +1052,14 @@ class ReadEngine:
         seen_ld = (c.vocab + 31) // 32
         if rp != 1.0 and self._seen is None:
             self._seen = torch.zeros(self.max_reads, seen_ld, dtype=torch.int32, device=dev)
+        smp = self._sampling(sample)
         gs = _lib.GenState(cur_ids=_lib.ptr(self.cur_ids), lens=_lib.ptr(self.lens), n_gen=_lib.ptr(self.n_gen),
                            finished=_lib.ptr(self.finished), out_tokens=_lib.ptr(self.out_tokens),
                            rope_delta=_lib.ptr(self.rope_delta), max_new=max_new, min_new=min_new,
                            n_eos=min(len(c.eos_ids), 4), pad_id=c.pad_id, eos=eos,
                            seen=_lib.ptr(self._seen) if rp != 1.0 else None, seen_ld=seen_ld, rep_penalty=rp,
-                           status=_lib.ptr(self.status))
+                           status=_lib.ptr(self.status), do_sample=smp[0], temperature=smp[1], top_k=smp[2], top_p=smp[3],
+                           seed=smp[4], read_ids=_lib.ptr(self.read_ids))
         # idle slots decode a finished one-token read (cheap) until a real read moves in
         self.finished[:R].fill_(1)
         self.lens[:R].fill_(1)
@@ -1064,6 +1102,7 @@ class ReadEngine:
             sl = torch.tensor(slots, dtype=torch.long, device=dev)
             admit_keep.append((d_ids, d_img, d_pos, d_seq, emb))  # alive until the next host sync of the decode loop
             self.lens[sl] = d_seq
+            self.read_ids[sl] = torch.tensor(reads, dtype=torch.int32, device=dev)
             self.rope_delta[sl] = torch.from_numpy(delta).to(dev)
             self.n_gen[sl] = 0
             self.finished[sl] = 0
@@ -1092,7 +1131,7 @@ class ReadEngine:
             for s, r in zip(slots, reads):
                 slot_read[s] = r
 
-        key = (R, splits, max_new, min_new, rp, tuple(c.eos_ids), c.pad_id)
+        key = (R, splits, max_new, min_new, rp, tuple(c.eos_ids), c.pad_id, smp)
         while True:
             free = [s for s in range(R) if slot_read[s] < 0]
             if free and nxt < N and (len(free) >= (min_admit or max(1, R // 8)) or len(free) == R or N - nxt <= len(free)):

@@ -38,7 +38,7 @@ typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
 #define HWOCR_EPI_GELU_TANH 6 /* nn.GELU(approximate="tanh"): SigLIP MLP (HF siglip/modeling_siglip.py:310-322) */
 #define HWOCR_EPI_GEGLU 7     /* SWIGLU's interleaved tile pairs with the tanh GELU as gate: Gemma MLP (HF gemma/modeling_gemma.py:84-97) */
 
-#define HWOCR_ABI_VERSION 7 /* bumped whenever a signature or struct layout below changes */
+#define HWOCR_ABI_VERSION 8 /* bumped whenever a signature or struct layout below changes */
 int hwocr_abi_version(void);
 /* text of the most recent launch failure in this process ("" if none): launcher name + HIP error */
 const char* hwocr_last_error(void);
@@ -194,6 +194,20 @@ int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_
                          int* finished, int* out_tokens, int max_new, int min_new, const int* eos, int n_eos,
                          int pad_id, unsigned* seen, int seen_ld, float rep_penalty, hwocr_stream_t stream);
 
+/* generate(do_sample=True): temperature -> top-k -> top-p -> one multinomial draw per read, then the same bookkeeping as
+ * hwocr_argmax_advance (replaces HF generation/logits_process.py Temperature / TopK / TopP warpers and the softmax +
+ * torch.multinomial of generation/utils.py:_sample as reached from /root/reference/ocr_agent/tools.py:765 when the checkpoint's
+ * generation_config.json says do_sample).  The procedure is exact integer arithmetic ("hwocr sampling v1", spelled out in
+ * oracle/sampling.py and DESIGN.md): fixed-point weights, radix-selected thresholds (ties at a threshold are kept whole),
+ * Philox4x32-10 keyed by `seed` with counter (read_ids[read] - or the row index when NULL -, step): a read's draws do not depend
+ * on batch layout.
+ * top_k <= 0 or >= V: off; top_p >= 1: off; temperature > 0.  debug (optional): [nseq][8] uint64 = max bits, top-k key, total mass,
+ * nucleus target mass, nucleus key, kept mass, draw target, token. */
+int hwocr_sample_advance(const void* logits, int ldl, int V, int nseq, int* cur_ids, int* lens, int* n_gen, int* finished,
+                         int* out_tokens, int max_new, int min_new, const int* eos, int n_eos, int pad_id, unsigned* seen,
+                         int seen_ld, float rep_penalty, float temperature, int top_k, float top_p, unsigned long long seed,
+                         const int* read_ids, unsigned long long* debug, hwocr_stream_t stream);
+
 /* ---- model-level entry points (what run_ocr's model.generate expands to) ----------------------------------- */
 
 #define HWOCR_VIT_QWEN2 0   /* LayerNorm, fc1 -> QuickGELU -> fc2 (HF modeling_qwen2_vl.py:421-437) */
@@ -292,6 +306,13 @@ typedef struct {
   float rep_penalty;
   int* status; /* device int32 (or NULL): HWOCR_STATUS_* bits raised by decode steps that met a read outside its invariants;
                 * the host reads it whenever it synchronises and treats non-zero as an error */
+  int do_sample; /* 0: greedy (hwocr_argmax_advance); 1: hwocr_sample_advance with the four fields below */
+  float temperature;
+  int top_k;
+  float top_p;
+  unsigned long long seed;
+  const int* read_ids; /* device int32 [reads] (or NULL: the slot index): the caller's number of the read in each slot; it enters the
+                        * RNG counter, so a read draws the same tokens whichever slot / batch it is decoded in */
 } hwocr_gen_state;
 
 /* prefill nseq reads laid out [nseq][rows_per_seq]; writes KV for reads seq0.. and the first generated token */

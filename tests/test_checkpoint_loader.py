@@ -64,15 +64,16 @@ def test_key_normalisation_of_older_layouts():
                    "model.language_model.layers.1.self_attn.q_proj.weight": 8, "model.vision_tower.post_layernorm.bias": 9}
 
 
-@pytest.mark.parametrize("gen,eos,pad,rp,note", [
+@pytest.mark.parametrize("gen,eos,pad,rp,note,smp", [
     ({"do_sample": True, "temperature": 0.01, "top_k": 1, "top_p": 0.001, "repetition_penalty": 1.05,
-      "eos_token_id": [505, 510], "pad_token_id": 511}, (505, 510), 511, 1.05, "argmax"),          # the Qwen2-VL model-card shape
-    ({"do_sample": True, "temperature": 0.8, "top_k": 50, "eos_token_id": 505}, (505,), 511, 1.0, "NOT what the reference would draw"),
-    ({"eos_token_id": 510}, (510,), 511, 1.0, ""),
+      "eos_token_id": [505, 510], "pad_token_id": 511}, (505, 510), 511, 1.05, "argmax", (False, 1.0, 0, 1.0)),  # the Qwen2-VL model-card shape
+    ({"do_sample": True, "temperature": 0.8, "top_k": 50, "eos_token_id": 505}, (505,), 511, 1.0, "hwocr_sample_advance", (True, 0.8, 50, 1.0)),
+    ({"do_sample": True, "top_p": 0.9, "eos_token_id": 505}, (505,), 511, 1.0, "hwocr_sample_advance", (True, 1.0, 50, 0.9)),  # HF defaults: T 1, top_k 50
+    ({"eos_token_id": 510}, (510,), 511, 1.0, "", (False, 1.0, 0, 1.0)),
 ])
-def test_generation_config_defaults(tmp_path, capsys, gen, eos, pad, rp, note):
-    """generation_config.json written by HF's own GenerationConfig.save_pretrained: EOS set, pad id and repetition penalty
-    are taken over; sampling settings that amount to the argmax pass silently, real sampling is declared unbuilt."""
+def test_generation_config_defaults(tmp_path, gen, eos, pad, rp, note, smp):
+    """generation_config.json written by HF's own GenerationConfig.save_pretrained: EOS set, pad id, repetition penalty and the
+    sampling settings are taken over (HF's defaults where the file is silent); top_k = 1 is the argmax and stays greedy."""
     import transformers as tf
 
     _write_dir(tmp_path, "qwen2_vl")
@@ -81,5 +82,4 @@ def test_generation_config_defaults(tmp_path, capsys, gen, eos, pad, rp, note):
     assert (tuple(cfg.eos_ids), cfg.repetition_penalty) == (eos, rp)
     assert cfg.pad_id == (gen.get("pad_token_id", engine.ModelConfig().pad_id))
     assert note in cfg.sampling_note
-    printed = capsys.readouterr().out
-    assert ("warning" in printed) == ("NOT" in note)
+    assert (cfg.do_sample, cfg.temperature, cfg.top_k, cfg.top_p) == smp

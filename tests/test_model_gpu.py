@@ -122,6 +122,37 @@ def test_graph_decode_equals_eager_and_oracle(eng):
             assert eager[r][k] == rt[k], f"read {r} step {k}: engine {eager[r][k]} oracle {rt[k]}"
 
 
+def test_sampled_reads_depend_on_seed_read_and_step_only(eng):
+    """generate(do_sample=True) through the engine: the same reads decoded as one batch, eagerly or through the graph replay, alone
+    (another slot, another batch) and through the slot-refilling stream draw the same tokens - the RNG counter is (read number, step);
+    another seed draws others; sample={} and top_k = 1 are the greedy path.  (The draw itself against the oracle: test_sampling_gpu.py.)"""
+    from handwritten_ocr_amd import engine
+
+    g = tiny_case("bf16")
+    cases = ["a", "b", "a"]
+    pages = [_page(eng, g, c) for c in cases]
+    prompts = [g[f"{c}.input_ids"].numpy() for c in cases]
+    n = 12
+    smp = dict(temperature=1.0, top_k=40, top_p=0.95, seed=7)
+    a = eng.generate(pages, prompts, max_new=n, min_new=n, sample=smp, use_graph=False)
+    b = eng.generate(pages, prompts, max_new=n, min_new=n, sample=smp, use_graph=True)
+    c = eng.generate(pages, prompts, max_new=n, min_new=n, sample=smp, use_graph=True)
+    assert a == b == c
+    assert a[0] != a[2], "the same page twice in a batch: two reads, two RNG streams"
+    one = [eng.generate([pages[i]], [prompts[i]], max_new=n, min_new=n, sample=smp, read_base=i)[0] for i in range(3)]
+    assert one == a
+    assert eng.generate_stream(pages, prompts, max_new=n, min_new=n, sample=smp, sync_every=4) == a
+    small = engine.ReadEngine(eng.cfg, tiny_weights(torch.bfloat16), max_reads=1, ctx=256, vit_batch=1, prefill_batch=1)
+    try:
+        assert small.generate_stream(pages, prompts, max_new=n, min_new=n, sample=smp, sync_every=4) == a  # one slot, refilled twice
+    finally:
+        small.close()
+    assert eng.generate(pages, prompts, max_new=n, min_new=n, sample=dict(smp, seed=8)) != a
+    greedy = eng.generate(pages, prompts, max_new=n, min_new=n)
+    assert eng.generate(pages, prompts, max_new=n, min_new=n, sample={}) == greedy
+    assert eng.generate(pages, prompts, max_new=n, min_new=n, sample=dict(temperature=0.7, top_k=1)) == greedy
+
+
 def test_eos_stops_a_read(eng):
     g = tiny_case("bf16")
     page, prompt = _page(eng, g, "a"), g["a.input_ids"].numpy()
