@@ -91,7 +91,7 @@ def _replay_readers(strategies: list, texts: list, fallback=None):
 
 
 def read_pages(image_paths: list, params: dict | None = None, cfg=config, workers: int = 8,
-               speculate_reocr: bool = False) -> tuple[list, list]:
+               speculate_reocr: bool = False, page_numbers: list | None = None) -> tuple[list, list]:
     """ONE batched engine pass over every strategy read of `image_paths`: (strategies, streams) with streams[p][k] = the
     generated token ids of page p under strategies[k].  `speculate_reocr`: also read the strategies a later `reocr` node
     would use."""
@@ -136,8 +136,10 @@ def read_pages(image_paths: list, params: dict | None = None, cfg=config, worker
         prepared = [sp.pages(p, strategies, processor.target_hw(p.shape[0], p.shape[1])) if isinstance(p, np.ndarray) else p
                     for p in prepared]
     flat = [im for page in prepared for im in page]
-    toks = tools.run_ocr_batch_tokens(flat, params)
     k = len(strategies)
+    if page_numbers is not None:  # number the reads by page in the WHOLE job (a rank holds a share): keys the sampling RNG
+        params = dict(params or {}, read_ids=[int(n) * k + j for n in page_numbers for j in range(k)])
+    toks = tools.run_ocr_batch_tokens(flat, params)
     return strategies, [toks[p * k: (p + 1) * k] for p in range(len(image_paths))]
 
 
@@ -236,7 +238,8 @@ def transcribe_folder(images: list, output_dir: Path, ground_truth_dir: Path | N
     mine = shard.shard(images, rank, world)
     sink = io.StringIO() if quiet else None
     with contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext():
-        strategies, streams = read_pages([str(p) for p in mine], params, speculate_reocr=bool(agents))
+        strategies, streams = read_pages([str(p) for p in mine], params, speculate_reocr=bool(agents),
+                                         page_numbers=shard.shard(list(range(len(images))), rank, world))
     streams = gather_reads(streams, len(images), len(strategies))
     if streams is None:  # not rank 0: its reads are on their way to rank 0
         return []

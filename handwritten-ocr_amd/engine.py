@@ -1027,8 +1027,9 @@ class ReadEngine:
 
     # ------------------------------------------------------------------------------------------ continuous batching
     def generate_stream(self, pages: list, prompts: list, max_new: int, min_new: int = 0, sync_every: int = 16,
-                        repetition_penalty: float | None = None, min_admit: int = 0, sample: dict | None = None) -> list[list[int]]:
-        """Reads (greedy or drawn, as `generate`; read i draws from the RNG stream of read number i) of ANY number of (page, prompt) pairs through the engine's `max_reads` decode slots, refilled as
+                        repetition_penalty: float | None = None, min_admit: int = 0, sample: dict | None = None,
+                        read_ids: list | None = None) -> list[list[int]]:
+        """Reads (greedy or drawn, as `generate`; read i draws from the RNG stream of read number read_ids[i], default i) of ANY number of (page, prompt) pairs through the engine's `max_reads` decode slots, refilled as
         reads finish (EOS or max_new): the lockstep `generate` keeps a whole batch decoding until its longest read is done,
         which with the reference's 2048-token budget (config.py:19) and pages of a few hundred tokens idles most slots.
         Every `sync_every` decode steps the host looks at the stop flags, harvests finished reads, and prefills new ones
@@ -1102,7 +1103,7 @@ class ReadEngine:
             sl = torch.tensor(slots, dtype=torch.long, device=dev)
             admit_keep.append((d_ids, d_img, d_pos, d_seq, emb))  # alive until the next host sync of the decode loop
             self.lens[sl] = d_seq
-            self.read_ids[sl] = torch.tensor(reads, dtype=torch.int32, device=dev)
+            self.read_ids[sl] = torch.tensor(reads if read_ids is None else [int(read_ids[r]) for r in reads], dtype=torch.int32, device=dev)
             self.rope_delta[sl] = torch.from_numpy(delta).to(dev)
             self.n_gen[sl] = 0
             self.finished[sl] = 0

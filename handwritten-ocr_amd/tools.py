@@ -117,8 +117,10 @@ def run_ocr_batch_tokens(images: list, params: dict | None = None) -> list[list[
         pages.append(page)
         prompts.append(ids)
     # continuous batching: reads stop at different lengths (EOS), freed decode slots take the next read
+    # (read_ids: the caller's numbering of the reads - it keys the sampling RNG, so that a sampled read does not depend on the shard)
     return model.generate_stream(pages, prompts, max_new=max_new, min_new=min_new,
-                                 repetition_penalty=params.get("repetition_penalty"))  # None: the checkpoint's default
+                                 repetition_penalty=params.get("repetition_penalty"),  # None: the checkpoint's default
+                                 read_ids=params.get("read_ids"))
 
 
 def decode_tokens(streams: list) -> list[str]:
