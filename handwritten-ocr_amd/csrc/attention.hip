@@ -675,8 +675,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 3 : 1) void attn_vit80_ker
 int launch_vit80(const PrefillArgs& a, int nseg, int heads, int max_len, hipStream_t st) {
   // long segments (pages: 5184 tokens): the one-wave-per-SIMD kernel of attention_vit80x.hip (256 queries per workgroup); short ones
   // keep 128-query workgroups so the grid still fills the chip.  HWOCR_VIT80_KERNEL = x | 12 | 4 forces a form (read per call, so a
-  // test can walk all three in one process): 12 = the 384-query / 12-wave form that x replaced (2.13-2.21 ms against 2.01-2.03 per
-  // 12-page launch; vision 2940 -> 2815 ms per 84 pages in the bench).
+  // test can walk all three in one process): 12 = the 384-query / 12-wave form that x replaced (2.13-2.21 ms against 2.07-2.12 per
+  // 12-page launch; vision 2876-2940 -> 2837 ms per 84 pages in the bench).
   const char* force = getenv("HWOCR_VIT80_KERNEL");
   const bool wide = force ? force[0] == 'x' : max_len >= 1536;
   const int waves = force && force[0] != 'x' ? (atoi(force) == 12 ? 12 : 4) : (max_len >= 1536 ? 12 : 4);

@@ -73,16 +73,18 @@ __device__ __forceinline__ f32x16 acc_read(int idx) {
 // attn_vit80x: the same product for long segments as ONE wave per SIMD.  4 waves x 64 queries (two 32-query blocks per wave),
 // the whole 512-register file per wave, and the overlap of the matrix and vector pipes arranged INSIDE the wave instead of
 // left to three lockstep waves per SIMD (whose phases coincide: 17 % of SIMD cycles had both pipes busy):
-//   phase A(t): S(t+1) = K(t+1).Q'^T - m (20 MFMAs) beside  the weights exp2(S(t)) of tile t still to do (20 of 32 pairs)
+//   phase A(t): S(t+1) = K(t+1).Q^T   (20 MFMAs)  beside  the weights exp2(S(t)c - m) of tile t still to do (20 of 32 pairs)
 //   phase B(t): O += V^T(t).P(t)      (24 MFMAs)  beside  the row maximum of S(t+1), the new m / alpha, its first 12 pairs
 // one MFMA then one vector group per gap, kept in place by sched_barrier(0); every K / V^T fragment feeds two MFMAs (both query
 // blocks) and is read two fragments ahead.  K / V^T tiles: register-staged (buffer loads in the gaps of phase A, ds_write in those
 // of phase B, two tiles ahead into a 4-deep ring of the LDS images of attn_vit80_kernel), one barrier per tile.  The running
 // maximum is per query (a lane's m moves only when its tile maximum exceeds it by more than `slack`); O is rescaled after phase B
 // when some lane's m moved.
-// Measured (12 pages x 16 heads x 5184 tokens, N(0,1) data, tools/bench_vit80x_stamps.py): 2553 cycles per 64-key tile at 1.82 GHz
-// = phase A 954 + phase B 1271 + barrier 292 + glue 36 (2848 at 1.93 GHz with a scale-and-subtract per score: the chip gives most of
-// a cycle saving back as clock); 2.01-2.03 ms per launch against 2.13-2.21 for the 12-wave form.  A lone
+// Measured (12 pages x 16 heads x 5184 tokens, N(0,1) data, tools/bench_vit80x_stamps.py): 2848 cycles per 64-key tile at 1.93 GHz
+// = phase A 1196 + phase B 1295 + barrier 309 + glue 48; 2.07-2.12 ms per launch against 2.13-2.21 for the 12-wave form.
+// (Folding the softmax scale into the queries and the running reference into the score MFMAs' initial accumulator - one v_exp per
+// weight, no scale-and-subtract - ran 2553 cycles at 1.82 GHz, 2.02 ms, but the extra bf16 rounding of q cost up to 3.4 % of an
+// output on rows with large scores (tests: test_attn_vit80_page_shape): dropped, the scores stay exact fp32 sums of bf16 products.)  A lone
 // wave pays the SUM of its issue costs (MFMA 8, v_exp 8, other VALU 4, ds_read_b128 ~16, a 1-KiB buffer load ~60, an LDS-DMA
 // piece ~100 even against an empty descriptor): 1408 cycles of matrix time per tile sit under ~2500 of issue.  Two waves per SIMD
 // do not escape it: an 8-wave / 512-query form (query fragments re-read from LDS, <= 256 registers, waves 4..7 staggered by one
@@ -125,14 +127,7 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
   for (int qb = 0; qb < 2; ++qb) {
     const bf16* qrow = Qp + (long)min(qi0 + 32 * qb, len - 1) * a.q_row + 8 * hh;
 #pragma unroll
-    for (int s = 0; s < 5; ++s) {
-      // the queries carry the softmax scale (times log2 e) from here on: the score MFMAs then deliver exp2 arguments, and with the
-      // running reference as their initial accumulator (below) a weight costs one v_exp_f32 - no scale-and-subtract per score.
-      // One more bf16 rounding of q (2^-9 relative per element, averaging out over the 80-term dot product).
-      const bf16x8 q = *(const bf16x8*)(qrow + 16 * s);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qf[qb][s][j] = f2bf(bf2f(q[j]) * a.scale_log2);
-    }
+    for (int s = 0; s < 5; ++s) qf[qb][s] = *(const bf16x8*)(qrow + 16 * s);
   }
   // V^T rows 80..87 of every stage: row 80 = 1.0, the rest 0 (never touched by the DMA)
   for (int i = tid; i < NSTG * 8 * 64; i += NT) {
@@ -209,16 +204,8 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
 #pragma unroll
     for (int idx = 0; idx < 6; ++idx) acc_zero(idx, z);
   }
-  // The running reference m of a query (lazy maximum) lives, negated, in the 16 registers the score MFMAs start from: S' = k.q' - m.
-  // A tile whose maximum exceeds the reference by more than `slack` moves it (rare): delta > 0, the scores in flight are re-based,
-  // O is rescaled by alpha = 2^-delta after phase B.
-  f32x16 ninit[2];
-  float delta[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f};
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ninit[qb][i] = 0.f;
-  const float slack = a.slack;
+  float m[2] = {NEG_BIG, NEG_BIG}, alpha[2] = {1.f, 1.f};
+  const float c2 = a.scale_log2, slack = a.slack;
 
   f32x16 S0[2][2], S1[2][2];     // scores^T of the tile being weighted / the tile being scored: [query block][key block]
   bf16x8 P0[2][2][2], P1[2][2][2];  // weights as PV operands: [query block][key block][half]
@@ -226,39 +213,27 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
   // one pair of weights: scores 2p, 2p+1 of group g = (query block, key block, half) -> one dword of the PV operand
   auto weigh = [&](auto& S, auto& P, int pair) {
     const int g = pair >> 2, p = pair & 3, qb = g >> 2, kb = (g >> 1) & 1, s2 = g & 1;
-    const float x0 = __builtin_amdgcn_exp2f(S[qb][kb][8 * s2 + 2 * p]);
-    const float x1 = __builtin_amdgcn_exp2f(S[qb][kb][8 * s2 + 2 * p + 1]);
+    const float x0 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[qb][kb][8 * s2 + 2 * p], c2, -m[qb]));
+    const float x1 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[qb][kb][8 * s2 + 2 * p + 1], c2, -m[qb]));
     P[qb][kb][s2][2 * p] = f2bf(x0);
     P[qb][kb][s2][2 * p + 1] = f2bf(x1);
     // a finished fragment is pinned where it was computed: without a use in this block LLVM sinks the whole group of exponentials
     // past the next branch, next to the MFMA that reads it - out of the MFMA gaps they were placed in
     if (p == 3) asm volatile("" : "+v"(P[qb][kb][s2]));
   };
-  // the row-maximum chain of one query block in single-instruction steps; scores are relative to the reference, so the maximum IS
-  // the excess over it (thr = slack; the prologue's tile 0 has no reference yet: thr = -inf, its maximum becomes the reference)
-  float mx[2];
-  auto maxstep = [&](auto& S, int qb, int k, float thr) {
+  // the row-maximum chain of one query block in 22 single-instruction steps
+  float mx[2], mnew[2];
+  auto maxstep = [&](auto& S, int qb, int k) {
     if (k == 0) mx[qb] = fmaxf(S[qb][0][0], S[qb][1][0]);
     else if (k < 16) mx[qb] = fmaxf(fmaxf(mx[qb], S[qb][0][k]), S[qb][1][k]);  // v_max3_f32
     else if (k == 16) {
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx[qb]), __float_as_uint(mx[qb]), false, false);
-      mx[qb] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // both halves of a query column
+      mx[qb] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * c2;  // both halves of a query column
     } else if (k == 17) {
-      delta[qb] = mx[qb] > thr ? mx[qb] : 0.f;
+      mnew[qb] = mx[qb] > m[qb] + slack ? mx[qb] : m[qb];
     } else if (k == 18) {
-      alpha[qb] = __builtin_amdgcn_exp2f(-delta[qb]);
-    }
-  };
-  // the reference moved: re-base the scores already computed against the old one, and the initial accumulators of the next tiles
-  auto rebase = [&](auto& S) {
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) S[qb][kb][i] -= delta[qb];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) ninit[qb][i] -= delta[qb];
+      alpha[qb] = __builtin_amdgcn_exp2f(m[qb] - mnew[qb]);
+      m[qb] = mnew[qb];
     }
   };
   constexpr int MAXSTEPS = 19;
@@ -288,14 +263,10 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         if (s == 0) {
-          if (weights) {  // steady state: start from minus the reference
-            Sn[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f % 3], qf[qb][s], ninit[qb], 0, 0, 0);
-          } else {
-            f32x16 z;
+          f32x16 z;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) z[i] = 0.f;
-            Sn[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f % 3], qf[qb][s], z, 0, 0, 0);
-          }
+          for (int i = 0; i < 16; ++i) z[i] = 0.f;
+          Sn[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f % 3], qf[qb][s], z, 0, 0, 0);
         } else {
           Sn[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f % 3], qf[qb][s], Sn[qb][kb], 0, 0, 0);
         }
@@ -334,11 +305,7 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int id = 4 * gap + u;
-              if (id < 2 * MAXSTEPS) maxstep(Sn, id & 1, id >> 1, slack);
-            }
-            if (gap == 9 && __any(delta[0] != 0.f || delta[1] != 0.f)) {
-              asm volatile("; reference moved");
-              rebase(Sn);
+              if (id < 2 * MAXSTEPS) maxstep(Sn, id & 1, id >> 1);
             }
           } else if (gap < 22) {
             weigh(Sn, Pn, gap - 10);
@@ -394,10 +361,11 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
       for (int pr = 12; pr < 32; ++pr) weigh(Sc, Pc, pr);
     }
     if (!next && (len & 63)) clear_tail_v(t);
+    const float m0 = m[0], m1 = m[1];
     STAMP(0)
     phaseB(stage_ptr(t), Pc, Sn, Pn, next_c, t + 2);
     STAMP(2)
-    if (next && __any(delta[0] != 0.f || delta[1] != 0.f)) rescale();
+    if (next && __any(m[0] != m0 || m[1] != m1)) rescale();
     __syncthreads();  // tile t + 2 is in LDS (this step's ds_writes), every wave has finished with the stage of tile t
   };
 
@@ -409,12 +377,12 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
   if (nt == 1 && (len & 63)) mask_tail(S0, 0);
 #pragma unroll
   for (int k = 0; k < MAXSTEPS; ++k) {
-    maxstep(S0, 0, k, -INFINITY);
-    maxstep(S0, 1, k, -INFINITY);
+    maxstep(S0, 0, k);
+    maxstep(S0, 1, k);
   }
-  rebase(S0);  // tile 0's maximum is the first reference (O is still zero: no rescale)
 #pragma unroll
   for (int pr = 0; pr < 12; ++pr) weigh(S0, P0, pr);
+  // (O is still zero: the first alpha needs no rescale)
   int t = 0;
   for (; t + 2 < nt; t += 2) {
     step(t, S0, P0, S1, P1, std::true_type{});

@@ -288,6 +288,37 @@ def test_attn_vit80_long_segments(kernel, lens, monkeypatch):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize("kernel", ["x", "12"])
+def test_attn_vit80_page_shape(kernel, monkeypatch):
+    """The bench's page: 5184 tokens (72 x 72 patches of a 1008 x 1008 page), the tower's buffer layout ([heads][rows][80] q / k,
+    [heads][80][rows] v^T, two pages on one row axis), scores with a spread of maxima so that the lazy reference moves on some
+    queries late in the sweep; against fp32 SDPA, and bit-reproducible run to run."""
+    monkeypatch.setenv("HWOCR_VIT80_KERNEL", kernel)
+    hd, heads, P, nimg = 80, 2, 5184, 2
+    rows, DH = nimg * P, heads * hd
+    q = randbf(heads, rows, hd, seed=51)
+    k = randbf(heads, rows, hd, seed=52)
+    k[:, P - 300:P - 290] *= 6.0          # a few late keys with large scores: the running reference moves after 4800 keys
+    v = randbf(heads, rows, hd, seed=53)
+    vt = torch.zeros(heads, hd, rows + 64, dtype=torch.bfloat16, device=DEV)[:, :, :rows]
+    vt.copy_(v.transpose(1, 2))
+    lens = torch.full((nimg,), P, dtype=torch.int32, device=DEV)
+    scale = hd ** -0.5
+    outs = []
+    for _ in range(2):
+        out = torch.zeros(rows, DH, dtype=torch.bfloat16, device=DEV)
+        rc = lib().hwocr_attn_prefill(p(q), p(k), p(vt), p(out), p(lens), nimg, heads, 1, hd, P, 0, P * hd, rows * hd, hd, P * hd, rows * hd,
+                                      hd, P, hd * (rows + 64), rows + 64, P * DH, DH, scale, 0, st())
+        assert rc == 0
+        sync()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    for i in range(nimg):
+        sl = slice(i * P, (i + 1) * P)
+        want = _sdpa_ref(q[:, sl].float(), k[:, sl].float(), v[:, sl].float(), False, scale)
+        assert_close_bf16(outs[0][sl].view(P, heads, hd), want, ulps=4.0, atol=4e-3, what=f"page {i}, kernel {kernel}")
+
+
 @pytest.mark.parametrize("hd,heads", [(80, 4), (32, 2)])
 def test_attn_varlen_windows(hd, heads):
     """Ragged windows packed on one row axis (Qwen2.5-VL windowed layers): starts are multiples of 4 rows only."""
