@@ -71,10 +71,11 @@ __device__ __forceinline__ int2 e4m3_pack8(const bf16x8& v, float inv) {
   hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
   return make_int2(lo, hi);
 }
-__device__ __forceinline__ void e4m3_emit_row(const bf16x8 (&o)[MAXC], int lane, int nch, unsigned char* dst, float* scale) {
+template <int NC>
+__device__ __forceinline__ void e4m3_emit_row(const bf16x8 (&o)[NC], int lane, int nch, unsigned char* dst, float* scale) {
   float amax = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i)
+  for (int i = 0; i < NC; ++i)
     if (lane + 64 * i < nch)
 #pragma unroll
       for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf2f(o[i][e])));
@@ -82,7 +83,7 @@ __device__ __forceinline__ void e4m3_emit_row(const bf16x8 (&o)[MAXC], int lane,
   const float inv = amax > 0.f ? 448.0f / amax : 0.f;
   if (lane == 0) *scale = amax > 0.f ? amax / 448.0f : 1.0f;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i)
+  for (int i = 0; i < NC; ++i)
     if (lane + 64 * i < nch) *(int2*)(dst + (lane + 64 * i) * 8) = e4m3_pack8(o[i], inv);
 }
 
@@ -90,15 +91,18 @@ struct LayerNormArgs {
   const bf16* x; const bf16* w; const bf16* b; bf16* out; int rows, D, ldx, ldo; float eps;
   unsigned char* q8; float* q8s; int ldq;  // q8 != NULL: the bf16 row is not stored, its E4M3 codes + scale are
 };
+// NC = 16-byte chunks per lane (row width <= 512 NC): sized to the row, the registers of an 8-chunk instance (184 VGPRs, 2 waves per
+// SIMD) left too few rows in flight per CU to cover the memory latency - 2.0 TB/s at the tower's 1280-wide rows
+template <int NC>
 __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= a.rows) return;
   const int nch = a.D >> 3;
-  float x[MAXC][8];
+  // grid-stride over rows (HWOCR_LN_GRID workgroups, default 4096)
+  for (int row = blockIdx.x * 4 + w; row < a.rows; row += gridDim.x * 4) {
+  float x[NC][8];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       const bf16x8 v = *(const bf16x8*)(a.x + (long)row * a.ldx + ch * 8);
@@ -109,14 +113,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
   const float mean = wave_sum(s) / a.D;
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i)
+  for (int i = 0; i < NC; ++i)
     if (lane + 64 * i < nch)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mean; ss += d * d; }
   const float rstd = 1.0f / sqrtf(wave_sum(ss) / a.D + a.eps);
-  bf16x8 o[MAXC];
+  bf16x8 o[NC];
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       const bf16x8 g = *(const bf16x8*)(a.w + ch * 8);
@@ -127,6 +131,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
     }
   }
   if (a.q8) e4m3_emit_row(o, lane, nch, a.q8 + (long)row * a.ldq, a.q8s + row);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -142,16 +147,17 @@ struct RmsArgs {
   const int* row_index; int rows, D; float eps; int gemma;
   unsigned char* q8 = nullptr; float* q8s = nullptr; int ldq = 0;  // add_rmsnorm_kernel only: E4M3 codes + scale instead of out
 };
+template <int NC>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(RmsArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + w;
   if (row >= a.rows) return;
   const int src = a.row_index ? a.row_index[row] : row;
   const int nch = a.D >> 3;
-  float x[MAXC][8];
+  float x[NC][8];
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       const bf16x8 hv = *(const bf16x8*)(a.h + (long)src * a.ldh + ch * 8);
@@ -184,9 +190,9 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(RmsArgs a) {
   }
   if (!a.out && !a.q8) return;
   const float rstd = rsqrtf(wave_sum(ss) / a.D + a.eps);
-  bf16x8 o[MAXC];
+  bf16x8 o[NC];
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) {
+  for (int i = 0; i < NC; ++i) {
     const int ch = lane + 64 * i;
     if (ch < nch) {
       const bf16x8 g = *(const bf16x8*)(a.w + ch * 8);
@@ -963,12 +969,39 @@ extern "C" int hwocr_quant_rows_fp8(const void* X, void* Q, float* scale, int ro
   return hwocr_launch_status();
 }
 
+// the instance of a one-wave-per-row kernel whose chunk count fits the row: 1, 2, 3, 4 or 8 chunks of 8 elements per lane
+struct LaunchLayerNorm {
+  template <int NC> static void go(int grid, hipStream_t st, const LayerNormArgs& a) {
+    hipLaunchKernelGGL(layernorm_kernel<NC>, dim3(grid), dim3(256), 0, st, a);
+  }
+};
+struct LaunchAddRmsNorm {
+  template <int NC> static void go(int grid, hipStream_t st, const RmsArgs& a) {
+    hipLaunchKernelGGL(add_rmsnorm_kernel<NC>, dim3(grid), dim3(256), 0, st, a);
+  }
+};
+template <typename L, typename Args>
+static void launch_by_chunks(int D, int grid, hipStream_t st, const Args& a) {
+  const int nc = (D / 8 + 63) / 64;
+  if (nc <= 1) L::template go<1>(grid, st, a);
+  else if (nc == 2) L::template go<2>(grid, st, a);
+  else if (nc == 3) L::template go<3>(grid, st, a);
+  else if (nc == 4) L::template go<4>(grid, st, a);
+  else L::template go<MAXC>(grid, st, a);
+}
+
+static int ln_grid(int rows) {
+  static const int cap = [] { const char* e = getenv("HWOCR_LN_GRID"); return e ? atoi(e) : 4096; }();  // (62208 x 1280, cold: 75 us uncapped, 70 at 4096, 83 at 2048)
+  const int need = (rows + 3) / 4;
+  return need < cap ? need : cap;
+}
+
 extern "C" int hwocr_layernorm(const void* x, const void* w, const void* b, void* out, int rows, int D, int ldx,
                                int ldo, float eps, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldx % 8 || ldo % 8) return HWOCR_EINVAL;
   LayerNormArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)out, rows, D, ldx, ldo, eps, nullptr, nullptr, 0};
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  launch_by_chunks<LaunchLayerNorm>(D, ln_grid(rows), stream, a);
   return hwocr_launch_status();
 }
 
@@ -977,7 +1010,7 @@ extern "C" int hwocr_layernorm_fp8(const void* x, const void* w, const void* b, 
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (!q8 || !q8s || rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldx % 8 || ldq % 8 || ldq < D) return HWOCR_EINVAL;
   LayerNormArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)b, nullptr, rows, D, ldx, 0, eps, (unsigned char*)q8, q8s, ldq};
-  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  launch_by_chunks<LaunchLayerNorm>(D, ln_grid(rows), stream, a);
   return hwocr_launch_status();
 }
 
@@ -987,7 +1020,7 @@ extern "C" int hwocr_rmsnorm_fp8(const void* h, int ldh, const void* w, void* q8
   if (!q8 || !q8s || rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldh % 8 || ldq % 8 || ldq < D) return HWOCR_EINVAL;
   RmsArgs a{nullptr, 0, 0, 0, nullptr, (bf16*)h, ldh, (const bf16*)w, nullptr, 0, nullptr, rows, D, eps, gemma};
   a.q8 = (unsigned char*)q8; a.q8s = q8s; a.ldq = ldq;
-  hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+  launch_by_chunks<LaunchAddRmsNorm>(D, (rows + 3) / 4, stream, a);
   return hwocr_launch_status();
 }
 
@@ -1005,7 +1038,7 @@ extern "C" int hwocr_add_rmsnorm(const float* slabs, int nslab, long slab_stride
   else if (rows <= 512)
     hipLaunchKernelGGL(add_rmsnorm_row_kernel<512>, dim3(rows), dim3(512), 0, stream, a);
   else
-    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
+    launch_by_chunks<LaunchAddRmsNorm>(D, (rows + 3) / 4, stream, a);
   return hwocr_launch_status();
 }
 
