@@ -432,7 +432,7 @@ class ReadEngine:
         self.ctx = _ceil(ctx, 64)
         self.vit_batch = vit_batch
         self.prefill_batch = prefill_batch
-        self.attn_splits = attn_splits
+        self.attn_splits = attn_splits or int(os.environ.get("HWOCR_ATTN_SPLITS", "0"))  # 0: pick_attn_splits
         self.fp8 = bool(fp8)
         self.fp8_decode = self.fp8 and (os.environ.get("HWOCR_FP8_DECODE", "0") not in ("", "0") if fp8_decode is None else bool(fp8_decode))
         self.collect_timings = False
