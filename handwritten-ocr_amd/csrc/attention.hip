@@ -731,6 +731,8 @@ struct DecodeArgs {
 // DEC_HD: 128, or 256 (Gemma; row layout only, 4 waves: the merge buffer is WAVES x DEC_HD x 16 floats).
 // WPE: minimum waves per SIMD the register budget must allow.  The 8-wave form runs at its natural 145-159 VGPRs = one workgroup per
 // CU; capped to 128 (WPE = 4: two workgroups per CU) hipcc spills 27 dwords and the decode step went from 4.21 to 4.94 ms per token.
+// Keeping the NEXT block's 16 fragment loads in flight while the current block multiplies (double-buffered fragments: 256 VGPRs,
+// 9 dwords of scratch) measured 4.32 against 4.22 ms per token: the loop is not waiting on its own loads.
 template <bool TILED, int WAVES, int DEC_HD, int WPE = (DEC_HD == 256 ? 1 : (WAVES == 8 ? 2 : 3))>
 __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs a) {
   constexpr int KS = DEC_HD / 32, VD = DEC_HD / 16;  // k-steps of the score product, d-tiles of the PV product
