@@ -10,7 +10,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 8  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
+ABI_VERSION = 9  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
 
 P = C.c_void_p
 I = C.c_int
@@ -117,6 +117,8 @@ _HIP_SIGS = {
     "hwocr_gemm_skinny_variant": ([I, I, I, I, I, I, C.c_char_p, I], I),
     "hwocr_attn_decode_variant": ([I, I, I, C.c_char_p, I], I),
     "hwocr_decode_gemm_plan": ([C.POINTER(Decoder), I, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I)], I),
+    "hwocr_plan_begin": ([], I),
+    "hwocr_plan_end": ([C.c_char_p, I, C.POINTER(I)], I),
     "hwocr_tile_weights": ([P, P, I, I, I, P], I),
     "hwocr_tile_weights_fp8": ([P, P, I, I, I, P], I),
     "hwocr_gemm_skinny_w8": ([P, P, P, P, P, I, I, I, I, I, I, I, P], I),

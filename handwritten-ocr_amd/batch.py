@@ -237,9 +237,25 @@ def transcribe_folder(images: list, output_dir: Path, ground_truth_dir: Path | N
     images = [Path(p) for p in images]
     mine = shard.shard(images, rank, world)
     sink = io.StringIO() if quiet else None
-    with contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext():
-        strategies, streams = read_pages([str(p) for p in mine], params, speculate_reocr=bool(agents),
-                                         page_numbers=shard.shard(list(range(len(images))), rank, world))
+    err = None
+    try:
+        with contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext():
+            strategies, streams = read_pages([str(p) for p in mine], params, speculate_reocr=bool(agents),
+                                             page_numbers=shard.shard(list(range(len(images))), rank, world))
+    except Exception as e:  # noqa: BLE001  (reported to every rank below, then re-raised here)
+        err = e
+    if world > 1:
+        # a rank whose reads raised (unreadable image, HwocrError) must not leave the others waiting in the gather: everyone learns
+        # who failed first, and every rank leaves with an error
+        import torch
+        import torch.distributed as dist
+
+        dev = torch.device(f"cuda:{torch.cuda.current_device()}") if dist.get_backend() == "nccl" else None
+        bad = shard.failed_ranks(err is None, dev)
+        if bad and err is None:
+            raise RuntimeError(f"rank(s) {bad} failed while reading their pages; rank {rank} stops with them")
+    if err is not None:
+        raise err
     streams = gather_reads(streams, len(images), len(strategies))
     if streams is None:  # not rank 0: its reads are on their way to rank 0
         return []

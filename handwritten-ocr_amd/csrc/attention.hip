@@ -431,6 +431,7 @@ inline float attn_slack() {
 
 template <int WAVES>
 int launch_hd256(PrefillArgs a, int nseg, int heads, int max_len, hipStream_t st) {
+  HWOCR_PLAN("attn_hd256_kernel<%d> nseg=%d heads=%d group=%d max_len=%d", WAVES, nseg, heads, a.group, max_len);
   static bool done = false;
   if (!done) {
     hipFuncSetAttribute((const void*)attn_hd256_kernel<WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G256_STAGE);
@@ -446,6 +447,8 @@ template <int HD, bool CAUSAL>
 int launch_prefill(const PrefillArgs& a, int nseg, int heads, int max_len, hipStream_t st) {
   constexpr int HDP = (HD + 31) / 32 * 32;
   constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HDP * 144);
+  HWOCR_PLAN("attn_prefill_kernel<%d,%s> nseg=%d heads=%d group=%d max_len=%d tiled=%d varlen=%d", HD, CAUSAL ? "causal" : "full", nseg,
+             heads, a.group, max_len, a.kv_tiled, a.seg_off != nullptr);
   static bool done = false;
   if (!done) {
     hipFuncSetAttribute((const void*)attn_prefill_kernel<HD, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -683,6 +686,8 @@ int launch_vit80(const PrefillArgs& a, int nseg, int heads, int max_len, hipStre
   PrefillArgs b = a;
   b.heads = heads;
   b.nseg = nseg;
+  HWOCR_PLAN("%s nseg=%d heads=%d max_len=%d", wide ? "attn_vit80x_kernel" : waves == 12 ? "attn_vit80_kernel<12>" : "attn_vit80_kernel<4>",
+             nseg, heads, max_len);
   if (wide) {
     b.qblocks = (max_len + 255) / 256;
     b.slack = attn_slack();

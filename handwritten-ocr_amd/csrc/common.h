@@ -71,3 +71,17 @@ static inline int hwocr_launch_status_at(const char* where) {
   return HWOCR_ELAUNCH;
 }
 #define hwocr_launch_status() hwocr_launch_status_at(__func__)
+
+// Plan recording (hwocr_plan_begin / hwocr_plan_end, runtime.hip): while it is on for the calling thread every launcher
+// validates its arguments as usual, notes the kernel instance and geometry it WOULD launch and returns HWOCR_OK without touching
+// the device.  hwocr_vit_forward / hwocr_prefill run under it with placeholder pointers give the launch list of a configuration —
+// what tests/test_wide_variants.py holds against the parity cases (no GPU needed).
+bool hwocr_plan_on();
+void hwocr_plan_note(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+#define HWOCR_PLAN(...)            \
+  do {                             \
+    if (hwocr_plan_on()) {         \
+      hwocr_plan_note(__VA_ARGS__); \
+      return HWOCR_OK;             \
+    }                              \
+  } while (0)

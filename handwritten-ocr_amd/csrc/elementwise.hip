@@ -927,6 +927,7 @@ extern "C" int hwocr_patchify(const void* img, const void* lut, void* out, int n
   PatchifyArgs a{(const uint8_t*)img, (const bf16*)lut, (bf16*)out, row_src, nimg, H, W, H / patch, W / patch,
                  patch, merge, tps, 3 * tps * patch * patch, kpad, rows_per_img_ld};
   const long total = (long)nimg * a.gh * a.gw * (kpad / 8);
+  HWOCR_PLAN("patchify_kernel nimg=%d H=%d W=%d kpad=%d permuted=%d", nimg, H, W, kpad, row_src != nullptr);
   hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }
@@ -965,6 +966,7 @@ extern "C" int hwocr_quant_rows_fp8(const void* X, void* Q, float* scale, int ro
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (!X || !Q || !scale || rows <= 0 || K <= 0 || K % 8 || ldx % 8 || ldq % 8 || ldx < K || ldq < K) return HWOCR_EINVAL;
   QuantArgs a{(const bf16*)X, (unsigned char*)Q, scale, rows, K, ldx, ldq};
+  HWOCR_PLAN("quant_rows_fp8_kernel rows=%d K=%d", rows, K);
   hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }
@@ -980,6 +982,10 @@ struct LaunchAddRmsNorm {
     hipLaunchKernelGGL(add_rmsnorm_kernel<NC>, dim3(grid), dim3(256), 0, st, a);
   }
 };
+static int chunks_instance(int D) {  // NC of the instance launch_by_chunks picks
+  const int nc = (D / 8 + 63) / 64;
+  return nc <= 1 ? 1 : nc <= 4 ? nc : MAXC;
+}
 template <typename L, typename Args>
 static void launch_by_chunks(int D, int grid, hipStream_t st, const Args& a) {
   const int nc = (D / 8 + 63) / 64;
@@ -1001,6 +1007,8 @@ extern "C" int hwocr_layernorm(const void* x, const void* w, const void* b, void
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldx % 8 || ldo % 8) return HWOCR_EINVAL;
   LayerNormArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)out, rows, D, ldx, ldo, eps, nullptr, nullptr, 0};
+  HWOCR_PLAN("layernorm_kernel<NC=%d> fp8=0 rows=%d D=%d grid=%d trips=%d", chunks_instance(D), rows, D, ln_grid(rows),
+             ((rows + 3) / 4 + ln_grid(rows) - 1) / ln_grid(rows));
   launch_by_chunks<LaunchLayerNorm>(D, ln_grid(rows), stream, a);
   return hwocr_launch_status();
 }
@@ -1010,6 +1018,8 @@ extern "C" int hwocr_layernorm_fp8(const void* x, const void* w, const void* b, 
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (!q8 || !q8s || rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldx % 8 || ldq % 8 || ldq < D) return HWOCR_EINVAL;
   LayerNormArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)b, nullptr, rows, D, ldx, 0, eps, (unsigned char*)q8, q8s, ldq};
+  HWOCR_PLAN("layernorm_kernel<NC=%d> fp8=1 rows=%d D=%d grid=%d trips=%d", chunks_instance(D), rows, D, ln_grid(rows),
+             ((rows + 3) / 4 + ln_grid(rows) - 1) / ln_grid(rows));
   launch_by_chunks<LaunchLayerNorm>(D, ln_grid(rows), stream, a);
   return hwocr_launch_status();
 }
@@ -1020,6 +1030,7 @@ extern "C" int hwocr_rmsnorm_fp8(const void* h, int ldh, const void* w, void* q8
   if (!q8 || !q8s || rows <= 0 || D % 8 || D > 64 * 8 * MAXC || ldh % 8 || ldq % 8 || ldq < D) return HWOCR_EINVAL;
   RmsArgs a{nullptr, 0, 0, 0, nullptr, (bf16*)h, ldh, (const bf16*)w, nullptr, 0, nullptr, rows, D, eps, gemma};
   a.q8 = (unsigned char*)q8; a.q8s = q8s; a.ldq = ldq;
+  HWOCR_PLAN("add_rmsnorm_kernel<NC=%d> fp8=1 gemma=%d rows=%d D=%d nslab=0 gather=0", chunks_instance(D), gemma, rows, D);
   launch_by_chunks<LaunchAddRmsNorm>(D, (rows + 3) / 4, stream, a);
   return hwocr_launch_status();
 }
@@ -1033,6 +1044,11 @@ extern "C" int hwocr_add_rmsnorm(const float* slabs, int nslab, long slab_stride
   if (nslab > 0 && row_index) return HWOCR_EINVAL;
   RmsArgs a{slabs, nslab, slab_stride, ld_slab, (const bf16*)bias, (bf16*)h, ldh, (const bf16*)w, (bf16*)out, ldo,
             row_index, rows, D, eps, gemma};
+  if (hwocr_plan_on()) {
+    if (rows <= 512) hwocr_plan_note("add_rmsnorm_row_kernel<%d> gemma=%d rows=%d D=%d nslab=%d gather=%d", D <= 2048 ? 256 : 512, gemma, rows, D, nslab, row_index != nullptr);
+    else hwocr_plan_note("add_rmsnorm_kernel<NC=%d> fp8=0 gemma=%d rows=%d D=%d nslab=%d gather=%d", chunks_instance(D), gemma, rows, D, nslab, row_index != nullptr);
+    return HWOCR_OK;
+  }
   if (rows <= 512 && D <= 2048)
     hipLaunchKernelGGL(add_rmsnorm_row_kernel<256>, dim3(rows), dim3(256), 0, stream, a);
   else if (rows <= 512)
@@ -1049,6 +1065,7 @@ extern "C" int hwocr_vit_rope_split(const void* qkv, void* Q, void* K, void* VT,
   if (tokens <= 0 || tok_ld % 64 || tok_ld < tokens || hd % 16 || hd > 128) return HWOCR_EINVAL;
   VitRopeArgs a{(const bf16*)qkv, (bf16*)Q, (bf16*)K, (bf16*)VT, pos_h, pos_w, cos_tab, sin_tab,
                 tokens, tok_ld, heads, hd, (long)tok_ld * hd, (long)hd * tok_ld, interleaved ? 1 : 0};
+  HWOCR_PLAN("vit_rope_split_kernel tokens=%d heads=%d hd=%d interleaved=%d", tokens, heads, hd, interleaved ? 1 : 0);
   hipLaunchKernelGGL(vit_rope_split_kernel, dim3((tok_ld + 63) / 64, heads), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }
@@ -1063,6 +1080,7 @@ extern "C" int hwocr_mrope_kv_prefill(const void* qkv, void* Q, void* K, void* V
   MropeArgs a{(const bf16*)qkv, (bf16*)Q, (bf16*)K, (bf16*)VT, pos, (const bf16*)cos_tab,
               (const bf16*)sin_tab, rows, rows_per_seq, Hq, Hkv, sec0, sec1, k_seq, k_head, v_seq, v_head, v_row,
               kv_tiled};
+  HWOCR_PLAN("mrope_kv_prefill_kernel<%d> rows=%d Hq=%d Hkv=%d tiled=%d", head_dim, rows, Hq, Hkv, kv_tiled);
   if (head_dim == 128)
     hipLaunchKernelGGL(mrope_kv_prefill_kernel<128>, dim3((rows + 63) / 64, Hq + 2 * Hkv), dim3(256), 0, stream, a);
   else
@@ -1093,6 +1111,7 @@ extern "C" int hwocr_embed_splice(const int* ids, const int* img_row, const void
   if (rows <= 0 || D % 8) return HWOCR_EINVAL;
   EmbedArgs a{ids, img_row, (const bf16*)table, (const bf16*)img, (bf16*)out, rows, D, scale};
   const long total = (long)rows * (D / 8);
+  HWOCR_PLAN("embed_splice_kernel rows=%d D=%d spliced=%d", rows, D, img_row != nullptr);
   hipLaunchKernelGGL(embed_splice_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
   return hwocr_launch_status();
 }
@@ -1106,6 +1125,7 @@ extern "C" int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq
   if (seen && (seen_ld * 32 < V || !(rep_penalty > 0.f))) return HWOCR_EINVAL;
   SelectArgs a{(const bf16*)logits, ldl, V, cur_ids, lens, n_gen, finished, out_tokens, max_new, min_new,
                {0, 0, 0, 0}, n_eos, pad_id, (seen && rep_penalty != 1.0f) ? seen : nullptr, seen_ld, rep_penalty};
+  HWOCR_PLAN("argmax_advance_kernel nseq=%d V=%d penalty=%d", nseq, V, a.seen != nullptr);
   for (int k = 0; k < n_eos; ++k) a.eos[k] = eos[k];
   hipLaunchKernelGGL(argmax_advance_kernel, dim3(nseq), dim3(ARG_THREADS), 0, stream, a);
   return hwocr_launch_status();
@@ -1123,6 +1143,7 @@ extern "C" int hwocr_sample_advance(const void* logits, int ldl, int V, int nseq
   SampleArgs a{{(const bf16*)logits, ldl, V, cur_ids, lens, n_gen, finished, out_tokens, max_new, min_new,
                 {0, 0, 0, 0}, n_eos, pad_id, (seen && rep_penalty != 1.0f) ? seen : nullptr, seen_ld, rep_penalty},
                1.4426950408889634f / temperature, top_k, top_p, (unsigned)seed, (unsigned)(seed >> 32), read_ids, debug};
+  HWOCR_PLAN("sample_advance_kernel nseq=%d V=%d top_k=%d top_p=%g", nseq, V, top_k, (double)top_p);
   for (int k = 0; k < n_eos; ++k) a.g.eos[k] = eos[k];
   hipLaunchKernelGGL(sample_advance_kernel, dim3(nseq), dim3(ARG_THREADS), 0, stream, a);
   return hwocr_launch_status();

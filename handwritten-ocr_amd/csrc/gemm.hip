@@ -388,6 +388,7 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
     }
     return rc;
   }
+  HWOCR_PLAN("gemm_wide_kernel<epi=%d> M=%d N=%d K=%d tiles=%d", epi, M, N, K, a.tilesM * a.tilesN);
   dim3 grid(a.tilesM * a.tilesN), block(256);
   static bool attr_done = false;
   if (!attr_done) {
@@ -543,6 +544,12 @@ extern "C" int hwocr_gemm_skinny(const void* X, const void* W, const void* bias,
                                  hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (!skinny_args_ok(Bsz, N, K, ldx, ldw, ldo, epi, splitk, bias != nullptr)) return HWOCR_EINVAL;
+  if (hwocr_plan_on()) {
+    char name[128];
+    const int rc = hwocr_gemm_skinny_variant(Bsz, N, K, epi, splitk, w_tiled, name, sizeof(name));
+    if (rc == HWOCR_OK) hwocr_plan_note("%s rows=%d N=%d K=%d splitk=%d", name, Bsz, N, K, splitk);
+    return rc;
+  }
   if (skinny_takes_stream(Bsz, N, K, epi, splitk, w_tiled))
     return hwocr_gemm_stream(StreamArgs{(const bf16*)X, (const bf16*)W, (const bf16*)bias, out, Bsz, N, K, ldx, ldo, 0},
                              epi, splitk, stream);
@@ -593,6 +600,12 @@ extern "C" int hwocr_gemm_skinny_w8(const void* X, const void* W8t, const float*
                                     int N, int K, int ldx, int ldo, int epi, int splitk, hipStream_t stream) {
   (void)hipGetLastError();
   if (!X || !W8t || !wscale || !out || (K % 64) || !skinny_args_ok(Bsz, N, K, ldx, K, ldo, epi, splitk, bias != nullptr)) return HWOCR_EINVAL;
+  if (hwocr_plan_on()) {
+    char name[128];
+    const int rc = hwocr_gemm_skinny_variant(Bsz, N, K, epi, splitk, 2, name, sizeof(name));
+    if (rc == HWOCR_OK) hwocr_plan_note("%s rows=%d N=%d K=%d splitk=%d", name, Bsz, N, K, splitk);
+    return rc;
+  }
   StreamArgs a{(const bf16*)X, (const bf16*)W8t, (const bf16*)bias, out, Bsz, N, K, ldx, ldo, 0};
   a.wscale = wscale;
   return hwocr_gemm_stream(a, epi, splitk, stream);

@@ -549,7 +549,14 @@ void launch(const WideArgs& a, hipStream_t st) {
   WideArgs b = a;
   b.tilesM = (a.M + BM - 1) / BM;
   b.tilesN = (a.N + BN - 1) / BN;
-  if constexpr (EPI == EPI_LINEAR && !FP8) {  // measurement only: wrong results by construction
+  if (hwocr_plan_on()) {
+    hwocr_plan_note("gemm_wide256_kernel<epi=%d,%s,%s> M=%d N=%d K=%d tiles=%d grid=%d rounds=%d ktiles=%d", EPI,
+                    variant == 1 ? "lockstep" : "stagger", FP8 ? "e4m3" : "bf16", a.M, a.N, a.K, b.tilesM * b.tilesN, persistent_grid(b),
+                    (b.tilesM * b.tilesN + persistent_grid(b) - 1) / persistent_grid(b), a.K * (FP8 ? 1 : 2) / 128);
+    return;
+  }
+#ifdef HWOCR_DIAG  // diagnostic builds only (tools/diag_build.py): kernel variants that give WRONG results by construction
+  if constexpr (EPI == EPI_LINEAR && !FP8) {
     static const int ablate = [] { const char* e = getenv("HWOCR_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     if (ablate >= 7 && ablate <= 9) {  // store policies of the epilogue (results stay correct): 7 nt, 8 sc1, 9 sc0 sc1
       auto k = ablate == 7 ? gemm_wide256_kernel<EPI_LINEAR, true, false, 7>
@@ -577,6 +584,7 @@ void launch(const WideArgs& a, hipStream_t st) {
       return;
     }
   }
+#endif
   if (variant == 1) launch_one<EPI, false, FP8>(b, st);
   else launch_one<EPI, true, FP8>(b, st);
 }
@@ -593,18 +601,20 @@ int dispatch(const WideArgs& a, int epi, hipStream_t stream) {
     case EPI_VIT_QKV: launch<EPI_VIT_QKV, FP8>(a, stream); break;
     default: return HWOCR_EINVAL;
   }
-  return hwocr_launch_status();
+  return hwocr_plan_on() ? HWOCR_OK : hwocr_launch_status();
 }
 
 }  // namespace
 
 int hwocr_gemm_wide256(const WideArgs& a, int epi, hipStream_t stream) { return dispatch<false>(a, epi, stream); }
 
+#ifdef HWOCR_DIAG
 // timeline stamps of the last HWOCR_GEMM_ABLATE=10 launch: [workgroup][tile slot 0..63][start, loop end, epilogue end, -] ticks of 10 ns
 extern "C" int hwocr_debug_gemm_timeline(unsigned long long* host, int n) {
   if (!host || n <= 0 || n > TL_MAX) return HWOCR_EINVAL;
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timeline), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? HWOCR_OK : HWOCR_ELAUNCH;
 }
+#endif
 
 // X and W hold E4M3 bytes (ldx / ldw / K in elements = bytes), a.xscale / a.wscale their per-row fp32 scales
 int hwocr_gemm_wide256_fp8(const WideArgs& a, int epi, hipStream_t stream) {

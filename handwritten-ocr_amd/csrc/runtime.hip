@@ -71,6 +71,37 @@ inline int wide(const void* X, const void* W, const hwocr_w8& w8, void* q8, floa
 
 extern "C" int hwocr_abi_version(void) { return HWOCR_ABI_VERSION; }
 
+// ---- plan recording (common.h): one text line per launch the calling thread would have made
+#include <cstdarg>
+#include <cstring>
+#include <string>
+static thread_local bool t_plan_on = false;
+static thread_local std::string t_plan;
+bool hwocr_plan_on() { return t_plan_on; }
+void hwocr_plan_note(const char* fmt, ...) {
+  char line[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(line, sizeof(line), fmt, ap);
+  va_end(ap);
+  t_plan += line;
+  t_plan += '\n';
+}
+extern "C" int hwocr_plan_begin(void) {
+  t_plan.clear();
+  t_plan_on = true;
+  return HWOCR_OK;
+}
+// copies the recorded lines ('\n'-separated, NUL-terminated) into buf; *needed = bytes required (call again with a larger
+// buffer if it exceeds len).  Recording stops either way.
+extern "C" int hwocr_plan_end(char* buf, int len, int* needed) {
+  t_plan_on = false;
+  if (needed) *needed = (int)t_plan.size() + 1;
+  if (!buf || len < (int)t_plan.size() + 1) return HWOCR_EINVAL;
+  memcpy(buf, t_plan.c_str(), t_plan.size() + 1);
+  return HWOCR_OK;
+}
+
 static char g_last_error[256] = "";
 extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text) {
   snprintf(g_last_error, sizeof(g_last_error), "%s: HIP error %d (%s)", where, hip_error, text ? text : "?");

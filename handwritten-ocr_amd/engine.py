@@ -403,6 +403,82 @@ def decode_plan(cfg: ModelConfig, reads: int, fp8: bool = False) -> dict:
     return out
 
 
+def wide_plan(cfg: ModelConfig, hw: tuple[int, int], pages: int, reads: int, prompt_len: int, fp8: bool = False) -> list[str]:
+    """The launches of ONE hwocr_vit_forward over `pages` pages of hw = (H, W) pixels followed by ONE hwocr_prefill of `reads`
+    prompts of `prompt_len` tokens, as the library itself lists them under plan recording (hwocr_plan_begin: every launcher checks
+    its arguments, notes kernel instance + geometry and returns without touching the device) — so this is the launch sequence of
+    csrc/runtime.hip, not a restatement of it.  Host-only: the structs carry placeholder pointers.  One line per launch."""
+    lib = _lib.hip()
+    one = C.c_void_p(64)
+    w8 = _lib.W8(w=one, scale=one) if fp8 else _lib.W8()
+    pg, v25 = cfg.family == "paligemma", cfg.family == "qwen2_5_vl"
+    H, W = hw
+    gh, gw = H // cfg.patch_size, W // cfg.patch_size
+    P = gh * gw
+    Pp = _ceil(P, 64)
+    rows = pages * Pp
+    hp = cfg.vit_hd_pad
+    blocks = (_lib.VitBlock * cfg.depth)()
+    for l in range(cfg.depth):
+        for f in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"):
+            setattr(blocks[l], f, one)
+        blocks[l].windowed = 1 if (v25 and l not in cfg.fullatt) else 0
+        D, DH = cfg.embed_dim, cfg.num_heads * hp
+        # E4M3 copies exist where ReadEngine._w8 makes them: K a multiple of 128 and N of 8
+        blocks[l].qkv8 = w8 if D % 128 == 0 else _lib.W8()
+        blocks[l].proj8 = w8 if DH % 128 == 0 else _lib.W8()
+        blocks[l].fc18 = w8 if D % 128 == 0 else _lib.W8()
+        blocks[l].fc28 = w8 if cfg.mlp_dim % 128 == 0 else _lib.W8()
+    vit = _lib.Vit(depth=cfg.depth, dim=cfg.embed_dim, heads=cfg.num_heads, mlp_dim=cfg.mlp_dim, patch=cfg.patch_size,
+                   merge=cfg.merge, tps=cfg.tps, kpad=cfg.kpad, out_dim=cfg.hidden, kind=2 if pg else 1 if v25 else 0,
+                   head_pad=hp if hp != cfg.vit_hd else 0, eps=1e-6, patch_w=one, blocks=blocks, merger_ln_w=one, merger_ln_b=one,
+                   merger_fc1_w=one, merger_fc1_b=one, merger_fc2_w=one, merger_fc2_b=one, rope_cos=one, rope_sin=one,
+                   pixel_lut=one, patch_b=one, pos_embed=one, qk_interleaved=1)
+    ws = _lib.VitWs(**{k: one for k in ("patches", "x", "xn", "qkv", "q", "k", "vt", "attn", "mlp", "merge_mid")})
+    if fp8:
+        ws.q8, ws.q8s = one, one
+    lay = _lib.VitLayout(pos_h=one, pos_w=one, seg_lens=one)
+    if v25:
+        _, win_lens = imageproc.window_order(gh, gw, cfg.merge, cfg.window_size, cfg.patch_size)
+        lay.row_src = lay.win_off = lay.win_lens = one
+        lay.nwin, lay.max_win = pages * len(win_lens), int(win_lens.max())
+    layers = (_lib.DecLayer * cfg.layers)()
+    HD = cfg.head_dim
+    for l in range(cfg.layers):
+        for f in ("in_norm_w", "qkv_w", "qkv_b", "o_w", "post_norm_w", "gate_up_w", "down_w", "qkv_wt", "o_wt", "gate_up_wt", "down_wt"):
+            setattr(layers[l], f, one)
+        if pg:
+            layers[l].qkv_b = None
+        layers[l].qkv8 = layers[l].gate_up8 = w8 if cfg.hidden % 128 == 0 else _lib.W8()
+        layers[l].o8 = w8 if (cfg.q_heads * HD) % 128 == 0 else _lib.W8()
+        layers[l].down8 = w8 if cfg.inter % 128 == 0 else _lib.W8()
+    dec = _lib.Decoder(layers=cfg.layers, hidden=cfg.hidden, Hq=cfg.q_heads, Hkv=cfg.kv_heads, inter=cfg.inter, vocab=cfg.vocab,
+                       sec0=16, sec1=40, head_dim=HD, gemma=1 if pg else 0, eps=cfg.eps, embed_scale=1.0, embed=one, lm_head=one,
+                       lm_head_t=one, final_norm_w=one, L=layers, rope_cos=one, rope_sin=one, max_pos=4096)
+    dws = _lib.DecWs(**{k: one for k in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "logits")})
+    if fp8:
+        dws.q8, dws.q8s = one, one
+    Tp = _ceil(prompt_len, 64)
+    kv = _lib.Kv(k=one, vt=one, nseq_max=max(reads, 1), ctx=_ceil(Tp + 64, 64), tiled=1 if HD == 128 else 0)
+    eos = (C.c_int * 4)(0, 0, 0, 0)
+    gs = _lib.GenState(cur_ids=one, lens=one, n_gen=one, finished=one, out_tokens=one, rope_delta=one, max_new=8, min_new=0,
+                       n_eos=1, pad_id=0, eos=eos, seen=None, seen_ld=0, rep_penalty=1.0, status=one, do_sample=0,
+                       temperature=1.0, top_k=0, top_p=1.0, seed=0, read_ids=one)
+    _lib.check(lib.hwocr_plan_begin(), "hwocr_plan_begin")
+    try:
+        rc1 = lib.hwocr_vit_forward(C.byref(vit), C.byref(ws), one, pages, H, W, Pp, C.byref(lay), one, None) if pages > 0 else 0
+        rc2 = lib.hwocr_prefill(C.byref(dec), C.byref(dws), C.byref(kv), C.byref(gs), one, one, one, one, one, one, reads, Tp, 0,
+                                prompt_len, None) if reads > 0 else 0
+    finally:
+        need = C.c_int()
+        lib.hwocr_plan_end(None, 0, C.byref(need))
+        buf = C.create_string_buffer(need.value)
+        lib.hwocr_plan_end(buf, len(buf), C.byref(need))
+    _lib.check(rc1, "hwocr_vit_forward (plan)")
+    _lib.check(rc2, "hwocr_prefill (plan)")
+    return [l for l in buf.value.decode().split("\n") if l]
+
+
 class ReadEngine:
     VIT_MAX_GRID = 2048  # rows of the vision rotary table: the longest page side in patches (smart_resize admits 200:1 strips:
     #                      sqrt(1024^2 * 200) / 14 = 1035 patches at the reference's max_pixels); encode_pages checks it
@@ -458,23 +534,25 @@ class ReadEngine:
         self._tiled_keep.append(out)
         return out
 
-    def _w8(self, w2d: torch.Tensor) -> _lib.W8:
-        """E4M3 copy of a bound [N][K] weight + per-row scales (hwocr_quant_rows_fp8), or the empty pack."""
+    def _w8q(self, w2d: torch.Tensor):
+        """(hwocr_w8 pack, E4M3 codes [N][K] or None) of a bound weight: hwocr_quant_rows_fp8 per output feature, or the empty pack.
+        The codes tensor is returned beside the struct: a ctypes struct stored into a parent struct is copied field by field, so
+        a Python attribute hung on it does not survive `L.qkv8 = pack; L.qkv8` (the decode re-tiling never saw it)."""
         n, k = w2d.shape
         if not self.fp8 or k % 128 or n % 8:
-            return _lib.W8()
+            return _lib.W8(), None
         q = torch.empty(n, k, dtype=torch.uint8, device=self.dev)
         s = torch.empty(n, dtype=torch.float32, device=self.dev)
         _lib.check(self.lib.hwocr_quant_rows_fp8(_lib.ptr(w2d), _lib.ptr(q), _lib.ptr(s), n, k, k, k, _lib.stream_handle()),
                    "hwocr_quant_rows_fp8")
         self._keep += [q, s]
-        pack = _lib.W8(w=_lib.ptr(q), scale=_lib.ptr(s))
-        pack.codes, pack.scales = q, s  # (python-side handles for the decode re-tiling below)
-        return pack
+        return _lib.W8(w=_lib.ptr(q), scale=_lib.ptr(s)), q
 
-    def _w8_tiled(self, pack: _lib.W8):
-        """Byte-tiled copy of an E4M3 weight for the decode GEMMs (hwocr_tile_weights_fp8), or None."""
-        q = getattr(pack, "codes", None)
+    def _w8(self, w2d: torch.Tensor) -> _lib.W8:
+        return self._w8q(w2d)[0]
+
+    def _w8_tiled(self, q: torch.Tensor | None):
+        """Byte-tiled copy of an E4M3 weight's codes for the decode GEMMs (hwocr_tile_weights_fp8), or None."""
         if q is None or q.shape[0] % 16 or q.shape[1] % 64 or not self.fp8_decode:
             return None
         n, k = q.shape
@@ -640,12 +718,13 @@ class ReadEngine:
             L.o_w = P(w_o)
             L.post_norm_w = P(self._t(sd[p + "post_attention_layernorm.weight"]))
             L.gate_up_w, L.down_w = P(w_gu), P(w_down)
-            L.qkv8, L.o8, L.gate_up8, L.down8 = self._w8(w_qkv), self._w8(w_o), self._w8(w_gu), self._w8(w_down)
-            # decode copies: E4M3 codes byte-tiled for the streaming kernel where the layer has them (fp8 mode: half the weight
+            # decode copies: E4M3 codes byte-tiled for the streaming kernel where the layer has them (fp8_decode: half the weight
             # bytes per decode step), else bf16 in MFMA-fragment order (contiguous KiB per fragment load; 288 GB of HBM pays
             # for the copy)
-            for name, w, pack in (("qkv", w_qkv, L.qkv8), ("o", w_o, L.o8), ("gate_up", w_gu, L.gate_up8), ("down", w_down, L.down8)):
-                t8 = self._w8_tiled(pack)
+            for name, w in (("qkv", w_qkv), ("o", w_o), ("gate_up", w_gu), ("down", w_down)):
+                pack, codes = self._w8q(w)
+                setattr(L, name + "8", pack)
+                t8 = self._w8_tiled(codes)
                 if t8 is not None:
                     setattr(L, name + "8t", t8)
                 else:
@@ -664,8 +743,8 @@ class ReadEngine:
                                 embed_scale=float(c.hidden) ** 0.5,
                                 embed=P(embed), lm_head=P(head), final_norm_w=P(self._t(sd[t + "norm.weight"])), L=layers,
                                 rope_cos=P(self.dec_cos), rope_sin=P(self.dec_sin), max_pos=int(ang.shape[0]))
-        head8 = self._w8(head) if self.fp8_decode else _lib.W8()
-        head8t = self._w8_tiled(head8)
+        head8, head_codes = self._w8q(head) if self.fp8_decode else (_lib.W8(), None)
+        head8t = self._w8_tiled(head_codes)
         if head8t is not None:
             self.dec.lm_head8t = _lib.W8(w=head8t, scale=head8.scale)
             self._keep.append(head8)

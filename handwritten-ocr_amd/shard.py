@@ -40,8 +40,25 @@ def init_from_env(device_backend: bool = True) -> tuple[int, int, int]:
             # ranks sharing a GPU (rehearsal, HWOCR_ALLOW_SHARED_GPU=1): EVERY rank must take gloo, not only the surplus ones
             if int(os.environ.get("LOCAL_WORLD_SIZE", world)) > torch.cuda.device_count():
                 use_nccl = False
-        dist.init_process_group(backend="nccl" if use_nccl else "gloo", rank=rank, world_size=world)
+        # the collectives' timeout covers the longest stretch a rank legitimately waits for another: rank 0's host work on a whole
+        # folder (detokenise, node replay, agents, files) while the others sit in the closing barrier (RCCL's default: 10 minutes)
+        import datetime
+
+        timeout = datetime.timedelta(seconds=float(os.environ.get("HWOCR_DIST_TIMEOUT_S", "7200")))
+        dist.init_process_group(backend="nccl" if use_nccl else "gloo", rank=rank, world_size=world, timeout=timeout)
     return rank, local, world
+
+
+def failed_ranks(ok: bool, device=None) -> list[int]:
+    """Every rank reports whether its share of the work succeeded; returns the ranks that did not (same list on all ranks).  Called
+    BEFORE a data collective so that a rank whose reads raised still takes part in one — the others would otherwise wait in the
+    gather until the backend's timeout."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [] if ok else [0]
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device or "cpu")
+    flags = [torch.zeros_like(flag) for _ in range(dist.get_world_size())]
+    dist.all_gather(flags, flag)
+    return [r for r, f in enumerate(flags) if int(f) == 0]
 
 
 def shard(items: list, rank: int, world: int) -> list:

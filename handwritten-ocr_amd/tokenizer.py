@@ -98,8 +98,8 @@ class ByteTokenizer:
         self.special = {cfg.image_token_id, cfg.vision_start_id, cfg.vision_end_id, cfg.im_start_id, cfg.im_end_id,
                         cfg.pad_id, *cfg.eos_ids}
 
-    def encode(self, text: str) -> list[int]:
-        return list(text.encode("utf-8"))
+    def encode(self, text: str, add_special_tokens: bool = True) -> list[int]:
+        return list(text.encode("utf-8"))  # (no post-processor: the flag changes nothing)
 
     def decode(self, ids, skip_special_tokens: bool = True) -> str:
         out = bytearray()
@@ -126,8 +126,11 @@ class HFTokenizer:
         self.cfg = cfg
         self.tok = Tokenizer.from_file(os.path.join(path, "tokenizer.json"))
 
-    def encode(self, text: str) -> list[int]:
-        return self.tok.encode(text, add_special_tokens=True).ids
+    def encode(self, text: str, add_special_tokens: bool = True) -> list[int]:
+        """add_special_tokens: run tokenizer.json's post-processor (what PreTrainedTokenizerFast.__call__ does on the whole rendered
+        prompt); False for PIECES of a prompt that the caller assembles around explicit special ids (a `<bos> $A` template —
+        hub Gemma tokenizers — would otherwise put a second <bos> in front of every piece)."""
+        return self.tok.encode(text, add_special_tokens=add_special_tokens).ids
 
     def decode(self, ids, skip_special_tokens: bool = True) -> str:
         return self.tok.decode([int(t) for t in ids], skip_special_tokens=skip_special_tokens)
@@ -178,8 +181,11 @@ class Processor:
             return ids
         if c.family == "paligemma":
             # "<image>" x n + "<bos>" + prompt + "\n" tokenised as one string whose specials split it (HF
-            # paligemma/processing_paligemma.py build_string_from_input): the text part is encoded WITH its newline
-            return np.asarray([c.image_token_id] * n_image_tokens + [c.bos_id] + enc(prompt + "\n"), dtype=np.int32)
+            # paligemma/processing_paligemma.py build_string_from_input): the text part is encoded WITH its newline, and WITHOUT
+            # the tokenizer's own specials — PaliGemmaProcessor switches add_bos_token off and writes the one <bos> itself
+            return np.asarray([c.image_token_id] * n_image_tokens + [c.bos_id] + enc(prompt + "\n", add_special_tokens=False),
+                              dtype=np.int32)
+        enc = lambda t: self.tokenizer.encode(t, add_special_tokens=False)  # noqa: E731  (pieces around explicit special ids)
         ids = ([c.im_start_id] + enc("system\n" + SYSTEM_TEXT) + [c.im_end_id] + enc("\n")
                + [c.im_start_id] + enc("user\n") + [c.vision_start_id] + [c.image_token_id] * n_image_tokens
                + [c.vision_end_id] + enc(prompt) + [c.im_end_id] + enc("\n") + [c.im_start_id] + enc("assistant\n"))

@@ -38,7 +38,7 @@ typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
 #define HWOCR_EPI_GELU_TANH 6 /* nn.GELU(approximate="tanh"): SigLIP MLP (HF siglip/modeling_siglip.py:310-322) */
 #define HWOCR_EPI_GEGLU 7     /* SWIGLU's interleaved tile pairs with the tanh GELU as gate: Gemma MLP (HF gemma/modeling_gemma.py:84-97) */
 
-#define HWOCR_ABI_VERSION 8 /* bumped whenever a signature or struct layout below changes */
+#define HWOCR_ABI_VERSION 9 /* bumped whenever a signature or struct layout below changes */
 int hwocr_abi_version(void);
 /* text of the most recent launch failure in this process ("" if none): launcher name + HIP error */
 const char* hwocr_last_error(void);
@@ -328,6 +328,15 @@ int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwoc
  * which = 0 qkv, 1 o, 2 gate/up, 3 down, 4 LM head; *w_tiled = 0 row-major, 1 fragment-tiled bf16, 2 byte-tiled E4M3 (hwocr_gemm_skinny_w8).
  * Only m's dimensions and the NULL-ness of the tiled weight pointers of m->L[0] / m->lm_head_t / m->lm_head8t are read.  Launches nothing. */
 int hwocr_decode_gemm_plan(const hwocr_decoder* m, int nseq, int which, int* N, int* K, int* epi, int* splitk, int* w_tiled);
+
+/* Plan recording: between hwocr_plan_begin() and hwocr_plan_end() every launcher of this library called on the SAME thread checks
+ * its arguments as usual, records one text line "<kernel instance> <geometry>" and returns HWOCR_OK without touching the device
+ * (pointers are never dereferenced on the host either, apart from the model / layout structs).  hwocr_vit_forward / hwocr_prefill /
+ * hwocr_decode_step under it list the launches of a configuration: tests/test_wide_variants.py holds that list against the parity
+ * cases.  hwocr_plan_end copies the '\n'-separated lines (NUL-terminated) into buf and stops recording; *needed = bytes required
+ * (HWOCR_EINVAL if len is smaller: call it again with a larger buffer). */
+int hwocr_plan_begin(void);
+int hwocr_plan_end(char* buf, int len, int* needed);
 
 /* capture one decode step into a HIP graph; replay it n times back-to-back on `stream` */
 int hwocr_decode_graph_create(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,

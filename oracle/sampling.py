@@ -18,7 +18,15 @@ read's tokens depend only on (seed, read index, step) — not on batch layout, g
   draw  r = Philox4x32-10(counter = (read, step, 0, 0), key = (seed_lo, seed_hi)); r64 = r[1] << 32 | r[0];
         target = (W_kept * r64) >> 64; token = the smallest id whose running kept mass (in id order) exceeds target
 
-Everything after w_i is integer arithmetic: the HIP kernel (csrc/elementwise.hip: sample_advance_kernel) must agree bit for bit."""
+Everything after w_i is integer arithmetic: the HIP kernel (csrc/elementwise.hip: sample_advance_kernel) must agree bit for bit.
+
+Known deviation from HF's TopKLogitsWarper (the kernel mirrors it bit for bit, so both deviate): keys are clamped at 64
+logits below the maximum, and a tie group at the threshold is kept whole.  If FEWER than k tokens lie within 64 logits of the
+maximum, the k-th key is the clamp itself and every token passes `q <= t`: the tokens HF would have cut keep their weight
+floor(2^32 * 2^(-d log2e / T)).  At d >= 64 that weight is 0 for T <= 2.88 (2^32 * 2^(-64 * 1.4427 / T) < 1), so the kept SET differs
+from HF's but the distribution does not; above that temperature each such token carries a weight of a few units in 2^32 (483 at
+T = 4, i.e. 1.1e-7 of the maximum's; V = 152 k tokens all sitting exactly 64 below the maximum: 1.7e-2 of its mass, the worst case).  The
+checkpoints of this path ship T <= 1; tests/test_sampling_oracle.py compares with HF's warpers in the un-clamped regime only."""
 from __future__ import annotations
 
 import numpy as np

@@ -89,6 +89,12 @@ def eng8(request):
     e = engine.ReadEngine(engine.preset("tinypg"), sd, max_reads=8, ctx=256, vit_batch=2, prefill_batch=2, fp8=True,
                           fp8_decode=request.param)
     assert e.fp8_decode == request.param and bool(e.dec.lm_head8t.w) == request.param
+    # every LAYER GEMM too (the byte-tiled codes were never bound, so only the LM head ran on E4M3): tinypg's widths
+    # (hidden 256, 2 x 256 attention, inter 512) are all multiples of 128, so each of the four has its E4M3 decode copy
+    L0 = e.dec.L[0]
+    for name in ("qkv", "o", "gate_up", "down"):
+        assert bool(getattr(L0, name + "8t")) == request.param, name
+        assert bool(getattr(L0, name + "_wt")) != request.param, name
     yield e
     e.close()
 

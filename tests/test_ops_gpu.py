@@ -47,11 +47,25 @@ def _swiglu_ref(acc, bias=None, geglu=False):
 
 
 # shapes with M >= 1024 and N >= 256 run the 256x256 8-wave kernel (gemm256.hip), the others the 128x128 one
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1000, 384, 1216), (257, 1536, 1536),
-                                   (1024, 256, 64), (1300, 512, 128), (2048, 768, 1216), (1111, 1000, 192),
-                                   (5184, 1280, 320)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3, 6])
-def test_gemm_wide(M, N, K, epi):
+WIDE_GEMM_SHAPES = [(128, 128, 64), (300, 200, 128), (1000, 384, 1216), (257, 1536, 1536), (1024, 256, 64), (1300, 512, 128),
+                    (2048, 768, 1216), (1111, 1000, 192), (5184, 1280, 320)]
+WIDE_GEMM_EPIS = [0, 1, 2, 3, 6]
+# The launch geometry of `python bench.py` (12 pages of 1008 x 1008 per tower launch = 62 208 rows, 16 prompts of 1344 padded rows
+# per prefill launch = 21 504 rows; engine.wide_plan lists them): every one of these has MORE tiles than the 256 workgroups of the
+# persistent grid, so a workgroup walks several tiles — next tile's prologue issued before the epilogue, counted hand-over wait,
+# residual rows fetched two passes ahead — which none of the shapes above does for epilogues 0 / 1 / 2 / 3 / 6.
+# Then one shape per remaining (epilogue, more than one round) class of the other presets: 7B / PaliGemma widths, K = 3456, 18 944.
+WIDE_BENCH_CASES = [
+    (62208, 1280, 1216, 0), (62208, 1280, 1280, 1), (62208, 5120, 1280, 2), (62208, 1280, 5120, 1),   # patch embed, proj, fc1, fc2
+    (15552, 5120, 5120, 3), (15552, 1536, 5120, 0),                                                    # merger
+    (21504, 2048, 1536, 0), (21504, 1536, 1536, 1), (21504, 1536, 8960, 1),                            # prefill qkv, o, down
+    (20000, 1280, 1280, 1), (15552, 5120, 1280, 2),          # ragged last row panel (M % 256 != 0) on the multi-tile path
+    (49152, 4352, 1152, 6), (49152, 2048, 1152, 0),          # SigLIP fc1 (tanh GELU) and the projector in bf16
+    (62208, 1280, 3456, 1), (21504, 3584, 18944, 1),         # Qwen2.5-VL-7B tower down / decoder down: 54 and 296 K tiles
+]
+
+
+def _check_gemm_wide(M, N, K, epi):
     x = randbf(M, K, scale=1.0, seed=1)
     w = randbf(N, K, scale=K ** -0.5, seed=2)
     bias = randbf(N, scale=0.5, seed=3)
@@ -67,10 +81,28 @@ def test_gemm_wide(M, N, K, epi):
     assert_close_bf16(out, want, ulps=2.0, atol=2e-3, what=f"gemm_wide epi={epi}", mag=mag)
 
 
+@pytest.mark.parametrize("M,N,K", WIDE_GEMM_SHAPES)
+@pytest.mark.parametrize("epi", WIDE_GEMM_EPIS)
+def test_gemm_wide(M, N, K, epi):
+    _check_gemm_wide(M, N, K, epi)
+
+
+@pytest.mark.parametrize("M,N,K,epi", WIDE_BENCH_CASES)
+def test_gemm_wide_bench_geometry(M, N, K, epi):
+    """Every workgroup of the persistent 256 x 256 kernel walks more than one tile (tiles > 256) — against the fp32 product."""
+    assert ((M + 255) // 256) * ((N + 255) // 256) > 256
+    _check_gemm_wide(M, N, K, epi)
+
+
 # with_bias: the Qwen2.5-VL vision MLP (gate_proj / up_proj carry a bias); (5184, 6912, 1280) is its page shape
+# (21504, 17920, 1536): the bench's prefill gate/up launch (5880 tiles, 23 per workgroup)
+WIDE_SWIGLU_SHAPES = [(200, 256, 128), (129, 17920 // 10, 1536), (1328, 1792, 1536), (2100, 608, 192), (5184, 6912, 1280),
+                      (21504, 17920, 1536)]
+WIDE_GEGLU_SHAPES = [(200, 256, 128), (1328, 1792, 1536), (4096, 8192, 2048)]   # the last: 512 tiles (Gemma's GeGLU over several rounds)
+
+
 @pytest.mark.parametrize("with_bias", [False, True])
-@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (129, 17920 // 10, 1536), (1328, 1792, 1536), (2100, 608, 192),
-                                   (5184, 6912, 1280)])
+@pytest.mark.parametrize("M,N,K", WIDE_SWIGLU_SHAPES)
 def test_gemm_wide_swiglu(M, N, K, with_bias):
     N = (N // 32) * 32
     x = randbf(M, K, seed=5)
@@ -88,7 +120,7 @@ def test_gemm_wide_swiglu(M, N, K, with_bias):
     assert_close_bf16(out, want, ulps=3.0, atol=2e-3, what="gemm_wide swiglu", mag=want.abs() * (1.0 + gate.abs()))
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (1328, 1792, 1536)])
+@pytest.mark.parametrize("M,N,K", WIDE_GEGLU_SHAPES)
 def test_gemm_wide_geglu(M, N, K):
     x = randbf(M, K, seed=5)
     w = randbf(N, K, scale=K ** -0.5, seed=6)
@@ -225,9 +257,12 @@ def _sdpa_ref(q, k, v, causal, scale):
     return (torch.softmax(s, -1) @ v).permute(1, 0, 2)
 
 
-@pytest.mark.parametrize("hd,Hq,Hkv,causal,tiled", [(80, 4, 4, False, 0), (128, 6, 2, True, 0), (32, 2, 2, False, 0),
-                                                     (64, 2, 1, True, 0), (128, 2, 2, False, 0), (128, 6, 2, True, 1),
-                                                     (256, 4, 1, False, 0), (256, 2, 1, True, 0)])
+# (64, 6, 6, False): the `small` preset's tower heads; (128, 28, 4, True, tiled): the 7B decoder's grouping
+ATTN_PREFILL_CASES = [(80, 4, 4, False, 0), (128, 6, 2, True, 0), (32, 2, 2, False, 0), (64, 2, 1, True, 0), (128, 2, 2, False, 0),
+                      (128, 6, 2, True, 1), (256, 4, 1, False, 0), (256, 2, 1, True, 0), (64, 6, 6, False, 0), (128, 28, 4, True, 1)]
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,causal,tiled", ATTN_PREFILL_CASES)
 def test_attn_prefill(hd, Hq, Hkv, causal, tiled):
     lens = [300, 64, 37, 129]
     nseg, Lp = len(lens), 320  # per-segment stride, multiple of 64
@@ -257,8 +292,14 @@ def test_attn_prefill(hd, Hq, Hkv, causal, tiled):
     assert torch.isfinite(out.float()).all()
 
 
+ATTN_VIT80_LONG_LENS = [[2000, 1537, 383, 769], [2048, 64, 1, 1600], [255, 257, 1999, 130]]
+ATTN_VARLEN_CASES = [(80, 4), (32, 2)]
+ATTN_HD256_LENS = [700, 513, 64, 1, 640, 333, 65, 128]
+MROPE_CASES = [(128, 16, 40, 0), (128, 16, 40, 1), (256, 128, 128, 0)]
+
+
 @pytest.mark.parametrize("kernel", ["x", "12", "4"])
-@pytest.mark.parametrize("lens", [[2000, 1537, 383, 769], [2048, 64, 1, 1600], [255, 257, 1999, 130]])
+@pytest.mark.parametrize("lens", ATTN_VIT80_LONG_LENS)
 def test_attn_vit80_long_segments(kernel, lens, monkeypatch):
     """Page-length segments take the one-wave-per-SIMD form of the head_dim-80 kernel (attention_vit80x.hip: 256 queries per
     workgroup, output accumulators in asm-owned AGPRs); the 12-wave (384 queries) and 4-wave (128) forms stay selectable
@@ -319,7 +360,7 @@ def test_attn_vit80_page_shape(kernel, monkeypatch):
         assert_close_bf16(outs[0][sl].view(P, heads, hd), want, ulps=4.0, atol=4e-3, what=f"page {i}, kernel {kernel}")
 
 
-@pytest.mark.parametrize("hd,heads", [(80, 4), (32, 2)])
+@pytest.mark.parametrize("hd,heads", ATTN_VARLEN_CASES)
 def test_attn_varlen_windows(hd, heads):
     """Ragged windows packed on one row axis (Qwen2.5-VL windowed layers): starts are multiples of 4 rows only."""
     lens = [64, 16, 32, 4, 64, 36, 8, 48, 12, 64]
@@ -424,7 +465,14 @@ def test_attn_decode_rejects_more_than_16_splits():
 
 
 # ------------------------------------------------------------------------------------------------ row-wise kernels
-@pytest.mark.parametrize("rows,D", [(5, 64), (1000, 1280), (33, 2048)])
+# (20 000 / 62 208 x 1280): two and four trips of the grid-stride loop (the grid is capped at 4096 workgroups = 16 384 rows; 62 208
+# rows is the bench's tower launch); 768 / 576 wide: the two-chunk instance (the `small` preset's decoder width, the tiny SigLIP);
+# (70 000 x 768): that instance on its second trip; 3584: the eight-chunk instance
+LAYERNORM_CASES = [(5, 64), (1000, 1280), (33, 2048), (20000, 1280), (62208, 1280), (5000, 768), (300, 576), (70000, 768), (49152, 1152),
+                   (600, 3584)]
+
+
+@pytest.mark.parametrize("rows,D", LAYERNORM_CASES)
 def test_layernorm(rows, D):
     x = randbf(rows, D, scale=3.0, seed=18)
     w = randbf(D, seed=19)
@@ -434,12 +482,24 @@ def test_layernorm(rows, D):
     sync()
     want = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-6)
     assert_close_bf16(out, want, ulps=1.0, atol=1e-3, what="layernorm")
+    if rows > 16384:  # a later trip of the loop must read ITS rows: row r of the second trip against row r of a launch of that slice alone
+        r0 = 16384 + 5
+        part = torch.empty(64, D, dtype=torch.bfloat16, device=DEV)
+        assert lib().hwocr_layernorm(p(x[r0:]), p(w), p(b), p(part), 64, D, D, D, 1e-6, st()) == 0
+        sync()
+        assert torch.equal(part, out[r0: r0 + 64])
 
 
 # D = 3584: Qwen2.5-VL-7B hidden size (512-thread row kernel / 7 chunks per lane); 1280 x 600 rows: its vision tower
-@pytest.mark.parametrize("rows,D,nslab", [(7, 1536, 0), (96, 1536, 6), (3, 256, 2), (126, 3584, 4), (600, 3584, 0),
-                                          (600, 1280, 0), (5, 4096, 3)])
-def test_add_rmsnorm(rows, D, nslab):
+# rows > 512: the wave-per-row kernel the tower (Qwen2.5-VL) and the prefill use — 768 / 1280 + 1536 / 2048 / 3584 wide = its 2 / 3 / 4 / 8
+# chunk instances; (21504, 1536) and (62208, 1280) are the bench's prefill and 7B-tower launches
+ADD_RMSNORM_CASES = [(7, 1536, 0), (96, 1536, 6), (3, 256, 2), (126, 3584, 4), (600, 3584, 0), (600, 1280, 0), (5, 4096, 3),
+                     (700, 768, 0), (700, 2048, 0), (21504, 1536, 0), (62208, 1280, 0), (600, 128, 0), (600, 1536, 3)]
+
+
+@pytest.mark.parametrize("gemma", [0, 1])
+@pytest.mark.parametrize("rows,D,nslab", ADD_RMSNORM_CASES)
+def test_add_rmsnorm(rows, D, nslab, gemma):
     h = randbf(rows, D, scale=2.0, seed=21)
     w = randbf(D, seed=22)
     bias = randbf(D, seed=23)
@@ -447,7 +507,7 @@ def test_add_rmsnorm(rows, D, nslab):
     h_in = h.clone()
     out = torch.empty_like(h)
     rc = lib().hwocr_add_rmsnorm(p(slabs) if nslab else None, nslab, rows * D, D, p(bias) if nslab else None, p(h), D,
-                                 p(w), p(out), D, None, rows, D, 1e-6, 0, st())
+                                 p(w), p(out), D, None, rows, D, 1e-6, gemma, st())
     assert rc == 0
     sync()
     x = h_in.float()
@@ -456,22 +516,30 @@ def test_add_rmsnorm(rows, D, nslab):
         x = rbf(rbf(y) + x)
         assert_close_bf16(h, x, ulps=1.0, atol=1e-3, what="residual write-back", mag=y.abs() + h_in.float().abs())
         x = h.float()
-    want = w.float() * rbf(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    xhat = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)
+    # Qwen2VLRMSNorm: w * bf16(xhat); GemmaRMSNorm (HF gemma/modeling_gemma.py:70-78): bf16(xhat * (1 + w)), all in fp32
+    want = xhat * (1.0 + w.float()) if gemma else w.float() * rbf(xhat)
     # the row statistic is summed in a different order than torch's -> the normalised value may round to the neighbouring
     # bf16 (1 ulp of it, up to 2 ulps of the product across a binade edge) before the weight multiply
     assert_close_bf16(out, want, ulps=2.5, atol=1e-3, what="rmsnorm")
 
 
-def test_add_rmsnorm_gather():
-    rows, D = 50, 1536
+# the final norm of a prefill chunk: last prompt row of every read gathered (2B / `small` widths, the 7B's 512-thread form, Gemma)
+ADD_RMSNORM_GATHER_CASES = [(1536, 0), (768, 0), (3584, 0), (2048, 1), (256, 1)]
+
+
+@pytest.mark.parametrize("D,gemma", ADD_RMSNORM_GATHER_CASES)
+def test_add_rmsnorm_gather(D, gemma):
+    rows = 50
     h = randbf(rows, D, seed=24)
     w = randbf(D, seed=25)
     idx = torch.tensor([49, 0, 17], dtype=torch.int32, device=DEV)
     out = torch.empty(3, D, dtype=torch.bfloat16, device=DEV)
-    assert lib().hwocr_add_rmsnorm(None, 0, 0, 0, None, p(h), D, p(w), p(out), D, p(idx), 3, D, 1e-6, 0, st()) == 0
+    assert lib().hwocr_add_rmsnorm(None, 0, 0, 0, None, p(h), D, p(w), p(out), D, p(idx), 3, D, 1e-6, gemma, st()) == 0
     sync()
     x = h[idx.long()].float()
-    want = w.float() * rbf(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    xhat = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)
+    want = xhat * (1.0 + w.float()) if gemma else w.float() * rbf(xhat)
     assert_close_bf16(out, want, ulps=1.5, atol=1e-3, what="rmsnorm gather")
 
 
@@ -559,9 +627,12 @@ def test_vit_rope_split(hd, heads, interleaved):
 
 
 # (M, K, heads, hd): the page-read shape of the Qwen towers and SigLIP-padded (16 x 80), ragged M (edge tiles), other head sizes
+VIT_QKV_CASES = [(5184, 1280, 16, 80), (1300, 256, 16, 80), (1088, 128, 8, 64), (2048, 192, 2, 128), (1024, 128, 16, 32),
+                 (62208, 1280, 16, 80), (49152, 1152, 16, 80)]   # the last two: the bench's tower launches (Qwen2-VL / SigLIP-padded)
+
+
 @pytest.mark.parametrize("fp8", [0, 1])
-@pytest.mark.parametrize("M,K,heads,hd", [(5184, 1280, 16, 80), (1300, 256, 16, 80), (1088, 128, 8, 64), (2048, 192, 2, 128),
-                                          (1024, 128, 16, 32)])
+@pytest.mark.parametrize("M,K,heads,hd", VIT_QKV_CASES)
 def test_gemm_vit_qkv_equals_gemm_then_rope_split(M, K, heads, hd, fp8):
     """hwocr_gemm_vit_qkv (rotary + head split + V transpose in the GEMM epilogue) against the two kernels it replaces,
     bit for bit, and against the fp32 restatement of HF's vision attention front end (modeling_qwen2_vl.py:239-248, :375-400)."""
@@ -660,7 +731,7 @@ def _rope_tables(maxpos, theta=1e6, hd=128):
 
 
 # hd 256 with sec0 = 128: plain RoPE on the first position axis (Gemma)
-@pytest.mark.parametrize("hd,sec0,sec1,tiled", [(128, 16, 40, 0), (128, 16, 40, 1), (256, 128, 128, 0)])
+@pytest.mark.parametrize("hd,sec0,sec1,tiled", MROPE_CASES)
 def test_mrope_kv_prefill(hd, sec0, sec1, tiled):
     Hq, Hkv, nseq, Tp, ctx = 4, 2, 2, 128, 256
     rows = nseq * Tp
@@ -947,12 +1018,34 @@ def test_quant_rows_fp8_bit_exact(rows, K):
     assert torch.equal(q.cpu(), wq.view(torch.uint8)), "E4M3 codes differ"
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (300, 264, 256), (1000, 384, 1152), (2065, 1024, 640), (4096, 1152, 4352)])
-@pytest.mark.parametrize("epi", [0, 1, 6])
+WIDE_FP8_SHAPES = [(64, 128, 128), (300, 264, 256), (1000, 384, 1152), (2065, 1024, 640), (4096, 1152, 4352)]
+WIDE_FP8_EPIS = [0, 1, 2, 6]
+# the fp8 bench's launches (PaliGemma-3B, 12 pages / 16 prompts per launch) whose workgroups walk several tiles, + a ragged one
+WIDE_FP8_BENCH_CASES = [(49152, 4352, 1152, 6), (49152, 1152, 4352, 1), (49152, 1152, 1280, 1), (66560, 2560, 2048, 0), (66560, 2048, 2048, 1),
+                        (12288, 4352, 1152, 6), (20000, 2048, 16384, 1),
+                        (15552, 5120, 1280, 2)]   # quick-GELU in E4M3: `bench.py --fp8` on the Qwen2-VL tower
+WIDE_FP8_GATED_SHAPES = [(1328, 1792, 1536), (8192, 8192, 2048)]  # the second: 1024 tiles
+
+
+def _fp8_gemm_ref(xq, xs, wq, ws):
+    """oracle/fp8_ref.gemm's arithmetic on the device (the float64 product of large shapes takes minutes on the host)."""
+    xd = xq.view(torch.float8_e4m3fn).float().double()
+    wd = wq.view(torch.float8_e4m3fn).float().double()
+    return (xd @ wd.t()).float() * (ws[None, :] * xs[:, None])
+
+
+def test_fp8_gemm_ref_on_the_device_equals_the_oracle():
+    from oracle import fp8_ref
+    xq, xs = _quant_gpu(randbf(70, 256, seed=3))
+    wq, ws = _quant_gpu(randbf(40, 256, scale=0.1, seed=4))
+    want = fp8_ref.gemm(xq.cpu().view(torch.float8_e4m3fn), xs.cpu(), wq.cpu().view(torch.float8_e4m3fn), ws.cpu())
+    assert torch.equal(_fp8_gemm_ref(xq, xs, wq, ws).cpu(), want)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(m, n, k, e) for (m, n, k) in WIDE_FP8_SHAPES for e in WIDE_FP8_EPIS] + WIDE_FP8_BENCH_CASES)
 def test_gemm_wide_fp8(M, N, K, epi):
     """The kernel against the exact scaled product of the SAME codes (oracle/fp8_ref.py): only fp32 accumulation order and
     the bf16 epilogue rounding separate them."""
-    from oracle import fp8_ref
     x = randbf(M, K, scale=1.0, seed=21)
     w = randbf(N, K, scale=K ** -0.5, seed=22)
     bias = randbf(N, scale=0.5, seed=23)
@@ -964,7 +1057,7 @@ def test_gemm_wide_fp8(M, N, K, epi):
                                    N, epi, st())
     assert rc == 0
     sync()
-    acc = fp8_ref.gemm(xq.cpu().view(torch.float8_e4m3fn), xs.cpu(), wq.cpu().view(torch.float8_e4m3fn), ws.cpu()).to(DEV)
+    acc = _fp8_gemm_ref(xq, xs, wq, ws)
     want = _epilogue_ref(acc, bias, res, epi)
     mag = (acc + bias.float()).abs() + (res.float().abs() if epi == 1 else 0.0)
     assert_close_bf16(out, want, ulps=2.0, atol=2e-3, what=f"gemm_wide_fp8 epi={epi}", mag=mag)
@@ -973,10 +1066,9 @@ def test_gemm_wide_fp8(M, N, K, epi):
     assert float((acc - exact).abs().mean() / exact.abs().mean()) < 0.06
 
 
+@pytest.mark.parametrize("M,N,K", WIDE_FP8_GATED_SHAPES)
 @pytest.mark.parametrize("geglu", [False, True])
-def test_gemm_wide_fp8_gated(geglu):
-    from oracle import fp8_ref
-    M, N, K = 1328, 1792, 1536
+def test_gemm_wide_fp8_gated(geglu, M, N, K):
     x = randbf(M, K, seed=25)
     w = randbf(N, K, scale=K ** -0.5, seed=26)
     xq, xs = _quant_gpu(x)
@@ -985,7 +1077,7 @@ def test_gemm_wide_fp8_gated(geglu):
     assert lib().hwocr_gemm_wide_fp8(p(xq), p(xs), p(wq), p(ws), None, None, p(out), M, N, K, K, K, N // 2, 0, 7 if geglu else 4,
                                      st()) == 0
     sync()
-    acc = fp8_ref.gemm(xq.cpu().view(torch.float8_e4m3fn), xs.cpu(), wq.cpu().view(torch.float8_e4m3fn), ws.cpu()).to(DEV)
+    acc = _fp8_gemm_ref(xq, xs, wq, ws)
     want = _swiglu_ref(acc, geglu=geglu)
     gate = rbf(acc.view(M, N // 32, 2, 16)[:, :, 0, :]).reshape(M, N // 2)
     assert_close_bf16(out, want, ulps=3.0, atol=2e-3, what="gemm_wide_fp8 gated", mag=want.abs() * (1.0 + gate.abs()))
@@ -1076,7 +1168,11 @@ def test_gemm_wide_fp8_rejects_bad_shapes():
 
 
 # > 512 rows: hwocr_add_rmsnorm then runs the same wave-per-row kernel as the fp8 form (the few-row kernel sums in another order)
-@pytest.mark.parametrize("rows,D", [(600, 128), (1000, 1152), (700, 2048), (520, 3584)])
+# (49152, 1152): the SigLIP tower launch of the fp8 bench (three trips of the LayerNorm's grid-stride loop); (66560, 2048): its prefill
+NORM_FP8_CASES = [(600, 128), (1000, 1152), (700, 2048), (520, 3584), (49152, 1152), (66560, 2048), (700, 768)]
+
+
+@pytest.mark.parametrize("rows,D", NORM_FP8_CASES)
 def test_norms_emitting_fp8_equal_norm_then_quantise(rows, D):
     """hwocr_layernorm_fp8 / hwocr_rmsnorm_fp8 = the bf16 norm followed by hwocr_quant_rows_fp8, bit for bit."""
     x = randbf(rows, D, scale=1.5, seed=31)
@@ -1100,7 +1196,7 @@ def test_norms_emitting_fp8_equal_norm_then_quantise(rows, D):
 
 def test_attn_prefill_hd256_long_reads():
     """The Gemma-prefill kernel at 8 reads (XCD-dealt grid), 8 query heads on one KV head, several K/V tiles and a ragged tail."""
-    hd, Hq, lens = 256, 8, [700, 513, 64, 1, 640, 333, 65, 128]
+    hd, Hq, lens = 256, 8, ATTN_HD256_LENS
     nseg, Lp = len(lens), 704
     q = randbf(nseg, Lp, Hq, hd, seed=41)
     k = randbf(nseg, 1, Lp, hd, seed=42)

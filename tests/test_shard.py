@@ -149,3 +149,57 @@ def test_ragged_width_gather_single_process_shapes():
     t = torch.zeros(0, 1, dtype=torch.int32)
     got = shard.gather_token_streams(t, torch.zeros(0, dtype=torch.int32))
     assert got[0][0].shape == (0, 1)
+
+
+# A rank whose reads raise must not leave the others waiting in the gather until the backend's timeout: every rank
+# learns who failed (shard.failed_ranks, before the data collective) and every rank leaves with an error, promptly.
+def _failing_folder_worker(rank, world, port, src, out_dir, q):
+    import contextlib
+    import io
+    import time
+
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from handwritten_ocr_amd import batch, tools
+
+    shard.init_from_env(device_backend=False)
+
+    def reads(images, params=None):
+        if rank == 1:
+            raise ValueError("unreadable page on rank 1")
+        return _scripted_tokens(images, params)
+
+    tools.run_ocr_batch_tokens = reads
+    tools.decode_tokens = lambda streams: [bytes(t).decode("utf-8") for t in streams]
+    t0 = time.time()
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            batch.transcribe_folder(batch.list_images(src), out_dir, quiet=True)
+        q.put((rank, "no error", time.time() - t0))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}", time.time() - t0))
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_stops_every_rank_with_an_error(tmp_path):
+    from PIL import Image
+
+    from handwritten_ocr_amd.synth import make_page
+
+    src = tmp_path / "pages"
+    src.mkdir()
+    for i in range(4):
+        Image.fromarray(make_page(i, 64, 80), "RGB").save(src / f"page{i:02d}.png")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_folder_worker, args=(r, 2, port, str(src), str(tmp_path / "out"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (msg, dt) for r, msg, dt in (q.get(timeout=120) for _ in range(2))}
+    for p in procs:
+        p.join(120)
+    assert got[1][0] == "ValueError: unreadable page on rank 1"
+    assert got[0][0].startswith("RuntimeError: rank(s) [1] failed"), got[0]
+    assert max(dt for _, dt in got.values()) < 60
+    assert not (tmp_path / "out").exists() or not os.listdir(tmp_path / "out")

@@ -108,3 +108,33 @@ def test_paligemma_prompt_ids_equal_hf_processor(kats):
         assert p.chat_ids(c["prompt"], c["image_tokens"]).tolist() == c["input_ids"]
     for d in pg["decode"]:
         assert p.decode(d["ids"], skip_special_tokens=True) == d["skip"]
+
+
+def test_paligemma_prompt_has_one_bos_when_the_tokenizer_prepends_its_own(kats, tmp_path):
+    """A hub Gemma tokenizer.json carries a `<bos> $A` TemplateProcessing post-processor; HF's PaliGemmaProcessor switches
+    add_bos_token off before it tokenises and writes the one <bos> itself (paligemma/processing_paligemma.py), so the prompt ids do
+    not change.  The golden directory was saved AFTER that switch (empty template), which hid a double <bos> here:
+    the same tokenizer with the post-processor put back must give the same ids as HF's processor."""
+    import json
+
+    pg = kats["paligemma"]
+    src = os.path.join(GOLD, "tokenizer_pg_tiny", "tokenizer.json")
+    with open(src) as f:
+        tj = json.load(f)
+    bos = pg["bos_token_id"]
+    bos_tok = next(t["content"] for t in tj["added_tokens"] if t["id"] == bos)
+    tj["post_processor"] = {"type": "TemplateProcessing",
+                            "single": [{"SpecialToken": {"id": bos_tok, "type_id": 0}}, {"Sequence": {"id": "A", "type_id": 0}}],
+                            "pair": [{"SpecialToken": {"id": bos_tok, "type_id": 0}}, {"Sequence": {"id": "A", "type_id": 0}},
+                                     {"Sequence": {"id": "B", "type_id": 1}}],
+                            "special_tokens": {bos_tok: {"id": bos_tok, "ids": [bos], "tokens": [bos_tok]}}}
+    with open(tmp_path / "tokenizer.json", "w") as f:
+        json.dump(tj, f)
+    cfg = engine.preset("tinypg")
+    cfg.image_token_id, cfg.bos_id, cfg.eos_ids, cfg.pad_id = pg["image_token_id"], bos, (pg["eos_token_id"],), pg["pad_token_id"]
+    tok = tokenizer.HFTokenizer(cfg, str(tmp_path))
+    assert tok.encode("abc")[0] == bos and tok.encode("abc", add_special_tokens=False)[0] != bos   # the post-processor is live
+    p = tokenizer.Processor(cfg, tok)
+    for c in pg["chat"]:
+        ids = p.chat_ids(c["prompt"], c["image_tokens"]).tolist()
+        assert ids == c["input_ids"] and ids.count(bos) == 1

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from handwritten_ocr_amd import _lib  # noqa: E402
 
+_lib._build.use_diag_library()  # the -DHWOCR_DIAG build (csrc/diag/): the shipped library has no ablation variants
 lib, p = _lib.hip(), _lib.ptr
 for M, N, K in ((62208, 5120, 1280), (62208, 1280, 5120), (62208, 5120, 128), (21248, 17920, 1536), (16384, 8192, 8192)):
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16)

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from handwritten_ocr_amd import _lib  # noqa: E402
 
 assert os.environ.get("HWOCR_GEMM_ABLATE") == "10", "run with HWOCR_GEMM_ABLATE=10"
+_lib._build.use_diag_library()  # the -DHWOCR_DIAG build (csrc/diag/): the shipped library has no ablation / timeline variants
 lib = C.CDLL(_lib._build.HIP_LIB)
 hip = _lib.hip()
 M, N, K = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (62208, 5120, 1280)
