@@ -146,3 +146,26 @@ def test_paligemma_full_width_two_layers_against_the_oracle():
     for r in range(2):
         _check_logits(logits[r], want_logits[r], toks[r], want_toks[r], f"paligemma-3b read {r}")
     eng.close()
+
+
+def test_qwen2vl_2b_full_depth_against_the_oracle():
+    """BASELINE config 2's model at FULL depth too (32 tower blocks, 28 decoder layers: 2.2 B parameters, the bench's weights): one
+    read of a 1008 x 1008 page, teacher-forced, against the oracle's full-depth read (≈10-15 s of host time — bench.py's
+    cpu_baseline leg is this very computation, so the test reuses it).  Same tolerances as the depth-2 cases."""
+    import bench
+    from handwritten_ocr_amd import engine, synth
+    from handwritten_ocr_amd.compat import config
+
+    cfg = engine.preset("qwen2-vl-2b")
+    sd = engine.random_state_dict(cfg, seed=0, device="cuda")
+    eng = engine.ReadEngine(cfg, sd, max_reads=4, ctx=2048, vit_batch=2, prefill_batch=2)
+    sd_cpu = {k: v.to("cpu") for k, v in engine.normalize_keys(sd).items()}
+    del sd
+    raw = np.ascontiguousarray(synth.make_page(3, 1024, 1024))
+    _, ora = bench.cpu_baseline(cfg, sd_cpu, raw, config.PREPROCESSING_STRATEGIES[2], 512, 3, n_dec=5)
+    del sd_cpu
+    r = bench.full_depth_parity(eng, ora)
+    eng.close()
+    assert r["steps"] == 6
+    assert r["mean_abs_err_over_scale"] <= 5e-3 and r["p999_abs_err_over_scale"] <= 3e-2 and r["max_abs_err_over_scale"] <= 6e-2, r
+    assert r["top1_agreement_on_decisive_steps"] == 1.0, r
