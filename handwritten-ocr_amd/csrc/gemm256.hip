@@ -343,6 +343,12 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
       if constexpr (EPI == EPI_VIT_QKV) {
         // Vision QKV projection with the rotary embedding, the head split and the V transpose folded in (what
         // vit_rope_split_kernel does to a [tokens][3 DH] intermediate).  DH % 256 == 0: a tile is all q, all k or all v.
+        // Every lane-derived index of this epilogue is recomputed per tile from a laundered copy of the lane id: left to itself
+        // hipcc hoists them (two integer divisions among them) out of the tile loop and, the main loop having no register to
+        // spare, carries them across it in scratch (2 VGPRs spilled in the bf16 instance, 23 in the E4M3 one).
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
+        const int lane = lane_l, c = lane & 15, q = lane >> 4;
         const hwocr_vit_split& vs = a.vs;
         const int hd = vs.hd, half = hd >> 1, quarter = hd >> 2, DH = vs.heads * hd;
         const int sec = en0 / DH, nsec = en0 - sec * DH;  // section (0 q, 1 k, 2 v) and the tile's first column inside it
@@ -353,9 +359,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
           // {2,3} = pair p + 1, p = 8nt + 2q of the wave's 32 pairs; pair P of the section = head P / half, feature P % half.
           bf16* dst = (bf16*)(sec ? vs.K : vs.Q);
           const int P0 = (nsec + 64 * wc) >> 1;
-          int fi[4];  // feature index i of the lane's first pair in every n-tile (the second is i + 1, same head, same axis)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) fi[nt] = (P0 + 8 * nt + 2 * q) % half;
+          // feature index i of the lane's first pair in n-tile nt (the second is i + 1, same head, same axis) = (P0 + 8 nt + 2 q) % half:
+          // one value kept, the other three stepped from it (8 <= half: a step wraps at most once) — four live registers fewer in
+          // the rotation loop (the kernel sat at 256 VGPRs + 2 spilled)
+          const int fi0 = (P0 + 2 * q) % half;
           // store side: chunk pch of a staged row = 8 features of group g = pch & 3, low (x1) half for pch < 4, high for pch >= 4
           const int pch = lane & 7;
           const int Pg = P0 + 8 * (pch & 3);
@@ -367,9 +374,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
               const int mt = 2 * pass + mh, ml = 16 * mh + c;
               const int mc = min(em0 + 128 * wr + 16 * mt + c, a.M - 1);
               const int ph = vs.pos_h[mc], pw = vs.pos_w[mc];
+              int i = fi0 - 8;
 #pragma unroll
               for (int nt = 0; nt < 4; ++nt) {
-                const int i = fi[nt];
+                i += 8;
+                if (i >= half) i -= half;
                 const int tab = (i < quarter ? ph * quarter + i : pw * quarter + i - quarter);
                 const f32x2 cs = *(const f32x2*)(vs.cos_tab + tab), sn = *(const f32x2*)(vs.sin_tab + tab);
                 float x[4];

@@ -65,7 +65,7 @@ WIDE_BENCH_CASES = [
 ]
 
 
-def _check_gemm_wide(M, N, K, epi):
+def _check_gemm_wide(M, N, K, epi, ulps=2.0):
     x = randbf(M, K, scale=1.0, seed=1)
     w = randbf(N, K, scale=K ** -0.5, seed=2)
     bias = randbf(N, scale=0.5, seed=3)
@@ -78,7 +78,7 @@ def _check_gemm_wide(M, N, K, epi):
     want = _epilogue_ref(acc, bias, res, epi)
     # 2 bf16 ulps of the largest rounded intermediate (bf16(acc+bias), the residual) + fp32 accumulation-order noise
     mag = (acc + bias.float()).abs() + (res.float().abs() if epi == 1 else 0.0)
-    assert_close_bf16(out, want, ulps=2.0, atol=2e-3, what=f"gemm_wide epi={epi}", mag=mag)
+    assert_close_bf16(out, want, ulps=ulps, atol=2e-3, what=f"gemm_wide epi={epi}", mag=mag)
 
 
 @pytest.mark.parametrize("M,N,K", WIDE_GEMM_SHAPES)
@@ -91,7 +91,11 @@ def test_gemm_wide(M, N, K, epi):
 def test_gemm_wide_bench_geometry(M, N, K, epi):
     """Every workgroup of the persistent 256 x 256 kernel walks more than one tile (tiles > 256) — against the fp32 product."""
     assert ((M + 255) // 256) * ((N + 255) // 256) > 256
-    _check_gemm_wide(M, N, K, epi)
+    # Activations: a 1-ulp flip of x = bf16(acc + bias) (accumulation order) moves x * s by 1 ulp(x), a flip of the rounded gate
+    # s = bf16(sigmoid(bf16(1.702 x))) by x * ulp(s) <= 0.75 ulp(x), the output rounding by 0.5 ulp: 2.25 ulps when all three
+    # coincide — which among 3e8 outputs they do (first GPU run of this case: 12 of 318 504 960 elements at 2.1-2.2 ulps, none
+    # beyond).  The small shapes above never meet the coincidence and keep 2 ulps; here the budget is the worst case, 2.5.
+    _check_gemm_wide(M, N, K, epi, ulps=2.0 if epi in (0, 1) else 2.5)
 
 
 # with_bias: the Qwen2.5-VL vision MLP (gate_proj / up_proj carry a bias); (5184, 6912, 1280) is its page shape
