@@ -358,7 +358,10 @@ def main() -> None:
     ap.add_argument("--prefill-batch", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the with_upload / host_preprocess_path / single-page legs")
-    ap.add_argument("--profile-steps", type=int, default=4, help="timed steps whose wide-GEMM launches carry HIP events")
+    ap.add_argument("--profile-steps", type=int, default=0, help="(ignored: every wide-GEMM launch of the timed region carries HIP events)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="batches in flight on the GPU: 2 = batch k's decode beside batch k+1's tower + prefill on two HIP streams "
+                         "(pipeline.LanePipeline); 1 = one batch at a time (the schedule of rounds 1-2)")
     ap.add_argument("--fp8", action="store_true",
                     help="E4M3 wide GEMMs for the vision tower and the prefill (BASELINE config 4; not the headline configuration)")
     args = ap.parse_args()
@@ -366,7 +369,7 @@ def main() -> None:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
-    from handwritten_ocr_amd import _lib, engine, gpupre, shard, text, tokenizer
+    from handwritten_ocr_amd import _lib, engine, gpupre, pipeline, shard, text, tokenizer
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if world_env != args.gpus:
@@ -395,18 +398,26 @@ def main() -> None:
         del sd  # (else kept: the CPU baseline runs the oracle on a host copy of these very weights; the engine aliases them)
     eng.collect_timings = True
     tok = tokenizer.ByteTokenizer(cfg, fold_unknown=True)
-    sp = gpupre.StrategyPages(dev)
+    pipe = pipeline.LanePipeline(eng, lanes=max(1, args.lanes))
+    for e in pipe.engines:
+        e.collect_timings = True
+    sps = {id(e): gpupre.StrategyPages(dev) for e in pipe.engines}   # (a lane's own scratch: two host threads preprocess side by side)
+    sp = sps[id(eng)]
     raws = raw_pages(args.pages, 1000 * rank, args.side)                    # host memory (what Image.open returns)
     raws_dev = [torch.from_numpy(r).to(dev) for r in raws]                   # the step's input, resident in HBM
     prompts = [synthetic_prompt(cfg, n_img_tokens)] * n_reads
     lib = _lib.hip()
     pre_ms = []
 
-    def read_and_merge(pages, n_pages):
-        toks = eng.generate(pages, prompts[: len(pages)], max_new=args.new_tokens, min_new=args.new_tokens)
+    def read_and_merge(pages, n_pages, e=None, hooks=None):
+        e = e or eng
+        toks = e.generate(pages, prompts[: len(pages)], max_new=args.new_tokens, min_new=args.new_tokens, hooks=hooks)
         t = torch.tensor(toks, dtype=torch.int32, device=dev)
         counts = torch.full((len(toks),), args.new_tokens, dtype=torch.int32, device=dev)
-        shard.gather_token_streams(t, counts, dst=0)
+        if hooks is not None:   # every rank must issue its gathers in batch order although two host threads drive each GPU
+            hooks.ordered(lambda: shard.gather_token_streams(t, counts, dst=0))
+        else:
+            shard.gather_token_streams(t, counts, dst=0)
         merged = []
         for p in range(n_pages):
             reads = [tok.decode(toks[p * args.reads + r]) for r in range(args.reads)]
@@ -415,39 +426,43 @@ def main() -> None:
             merged.append(text.merge_versions(reads))
         return merged
 
-    def step(src=None):
-        """src: device-resident raw pages (the timed configuration) or host arrays (upload inside the step)."""
+    def step(src=None, e=None, hooks=None):
+        """One step on engine (lane) e.  src: device-resident raw pages (the timed configuration) or host arrays (upload inside the
+        step).  Returns the lane's phase times of this step."""
+        e = e or eng
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        pages = [im for raw in (raws_dev if src is None else src) for im in sp.pages(raw, strategies, hw)]
+        pages = [im for raw in (raws_dev if src is None else src) for im in sps[id(e)].pages(raw, strategies, hw)]
         e1.record()
-        out = read_and_merge(pages, args.pages)
+        read_and_merge(pages, args.pages, e, hooks)
         pre_ms.append(e0.elapsed_time(e1))
-        return out
+        return dict(e.timings, preprocess_ms=pre_ms[-1])
+
+    def run_steps(k, src=None):
+        """k steps through the lanes (lanes == 1: one after the other on this thread's stream): their phase times in step order."""
+        return pipe.run([(lambda e, hooks, src=src: step(src, e, hooks)) for _ in range(k)])
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    phases = []
-    prof_steps = max(1, min(args.profile_steps, args.steps))
+    # W untimed warm-up steps; every lane must have run once (its decode graph is captured on its first batch), so with more lanes
+    # than W the warm-up is lanes steps long
+    warm = max(args.warmup, len(pipe.engines)) if args.warmup > 0 else 0
+    if warm:
+        run_steps(warm)
     barrier()
+    # HIP events around every wide-GEMM launch of the whole timed region (a few microseconds per launch: 0.2 % of a step)
     _lib.check(lib.hwocr_profile_enable(2 if args.fp8 else 1))
     t0 = time.perf_counter()
-    t_prof = None
-    for i in range(args.steps):
-        step()
-        phases.append(dict(eng.timings, preprocess_ms=pre_ms[-1]))
-        if i + 1 == prof_steps:  # events on the launch stream cost a few us per launch: sample the first steps only
-            t_prof = time.perf_counter() - t0
-            ms, fl, n = C.c_double(), C.c_double(), C.c_long()
-            _lib.check(lib.hwocr_profile_read(C.byref(ms), C.byref(fl), C.byref(n)))
-            lib.hwocr_profile_enable(0)
+    phases = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    prof_steps, t_prof = args.steps, elapsed
+    ms, fl, n = C.c_double(), C.c_double(), C.c_long()
+    _lib.check(lib.hwocr_profile_read(C.byref(ms), C.byref(fl), C.byref(n)))
+    lib.hwocr_profile_enable(0)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -457,13 +472,33 @@ def main() -> None:
     # reference's default host preprocessing, and BASELINE config 2 as literally stated (one page, its 3 reads in flight)
     extras = {}
     if world == 1 and not args.no_extras:
+        k_up = max(2, 2 * len(pipe.engines))
         torch.cuda.synchronize()
         t = time.perf_counter()
-        step(raws)
+        run_steps(k_up, raws)
         torch.cuda.synchronize()
-        up_s = time.perf_counter() - t
-        extras["with_upload"] = {"value": args.pages / up_s, "unit": "pages/s", "ms_per_step": up_s * 1e3,
-                                 "note": "raw pages start in host memory (pageable): 3 MB per page over PCIe inside the clock"}
+        up_s = (time.perf_counter() - t) / k_up
+        extras["with_upload"] = {"value": args.pages / up_s, "unit": "pages/s", "ms_per_step": up_s * 1e3, "steps": k_up,
+                                 "note": "the timed schedule with the raw pages starting in host memory (pageable): 3 MB per page over "
+                                         "PCIe inside the clock"}
+        if len(pipe.engines) > 1:
+            # one batch at a time on one stream (the schedule of rounds 1-2): what the overlap buys, the phase times of a batch that
+            # has the chip to itself, and the dominant kernel's rate when nothing runs beside it
+            _lib.check(lib.hwocr_profile_enable(2 if args.fp8 else 1))
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            seq = [step() for _ in range(2)]
+            torch.cuda.synchronize()
+            seq_s = (time.perf_counter() - t) / 2
+            ms1, fl1, n1 = C.c_double(), C.c_double(), C.c_long()
+            _lib.check(lib.hwocr_profile_read(C.byref(ms1), C.byref(fl1), C.byref(n1)))
+            lib.hwocr_profile_enable(0)
+            extras["one_batch_at_a_time"] = {
+                "value": args.pages / seq_s, "unit": "pages/s", "ms_per_step": seq_s * 1e3,
+                "phases_ms_per_step": {k[:-3]: float(np.mean([p[k] for p in seq])) for k in ("preprocess_ms", "vision_ms", "prefill_ms", "decode_ms")},
+                "dominant_kernel_alone": {"achieved": fl1.value / (ms1.value * 1e-3) / 1e12 if ms1.value > 0 else 0.0, "unit": "TFLOP/s",
+                                          "avg_launch_ms": ms1.value / max(1, n1.value), "launches": int(n1.value)},
+                "note": "--lanes 1: tower, prefill, decode of one batch back to back on one stream"}
         t = time.perf_counter()
         host_pages, host_s = host_strategy_pages(cfg, raws, args.reads, dev)
         same = all(torch.equal(a, b) for a, b in zip(host_pages[: 4 * args.reads],
@@ -488,6 +523,7 @@ def main() -> None:
         del one
         extras["single_page"] = {"latency_ms": float(np.median(lat[1:])), "pages_per_s": 1e3 / float(np.median(lat[1:])),
                                  "reads_in_flight": args.reads, "phases_ms": dict(eng.timings),
+                                 "decode_ms_per_token": eng.timings.get("decode_ms", 0.0) / max(1, args.new_tokens - 1),
                                  "note": "BASELINE config 2 as literally stated: one 1024x1024 page, its 3 strategy reads in flight"}
     if world > 1:
         dist.barrier()
@@ -501,6 +537,9 @@ def main() -> None:
     mean = lambda k: float(np.mean([p[k] for p in phases]))  # noqa: E731
     T = len(prompts[0])
     dec_ms = mean("decode_ms") / max(1, args.new_tokens - 1)
+    # the decode roofline is a statement about the decode kernels: taken from a batch that has the chip to itself when one was run
+    alone = extras.get("one_batch_at_a_time", {}).get("phases_ms_per_step")
+    dec_alone_ms = (alone["decode"] if alone else mean("decode_ms")) / max(1, args.new_tokens - 1)
     # decoder bytes per step: all layer weights + LM head (tied) + KV of every read at its mean context
     hd = cfg.head_dim
     per_layer = (cfg.q_heads + 2 * cfg.kv_heads) * hd * cfg.hidden + cfg.q_heads * hd * cfg.hidden + 3 * cfg.inter * cfg.hidden
@@ -534,6 +573,10 @@ def main() -> None:
                    "pages_per_step_per_gpu": args.pages, "reads_in_flight": n_reads, "prompt_tokens": T,
                    "image_tokens": int((prompts[0] == cfg.image_token_id).sum()), "new_tokens": args.new_tokens,
                    "single_page_latency_ms": extras.get("single_page", {}).get("latency_ms"),
+                   "lanes": len(pipe.engines),
+                   "schedule": ("two batches in flight per GPU: batch k's decode beside batch k+1's tower + prefill on two HIP streams "
+                                "(pipeline.LanePipeline; same tokens as one batch at a time)" if len(pipe.engines) > 1 else
+                                "one batch at a time: tower, prefill, decode back to back on one stream"),
                    "parallelism": f"replicas x{world}, pages sharded, RCCL gather of token streams"},
         "roofline": {"bound": "mfma",
                      "kernel": ("gemm_wide256_kernel<FP8> (E4M3 256x256x128 MFMA GEMM on v_mfma_f32_16x16x128_f8f6f4, 8 waves, staggered phases)"
@@ -546,9 +589,13 @@ def main() -> None:
                      "algorithmic_flops_per_launch": fl.value / max(1, n.value),
                      "share_of_step_time": ms.value / (t_prof * 1e3)},
         "phases_ms_per_step": {"preprocess": mean("preprocess_ms"), "vision": mean("vision_ms"), "prefill": mean("prefill_ms"),
-                               "decode": mean("decode_ms"), "decode_per_token": dec_ms},
-        "decode_roofline": {"bound": "hbm", "bytes_per_step": w_bytes + kv_bytes, "achieved": (w_bytes + kv_bytes) / (dec_ms * 1e-3) / 1e9,
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (w_bytes + kv_bytes) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                               "decode": mean("decode_ms"), "decode_per_token": dec_ms,
+                               "note": ("wall time of each phase of a batch WHILE the other lane's batch shares the chip (they overlap: the "
+                                        "sum exceeds ms_per_step); one_batch_at_a_time has the phases of a batch alone"
+                                        if len(pipe.engines) > 1 else "one batch at a time")},
+        "decode_roofline": {"bound": "hbm", "bytes_per_step": w_bytes + kv_bytes, "achieved": (w_bytes + kv_bytes) / (dec_alone_ms * 1e-3) / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (w_bytes + kv_bytes) / (dec_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "ms_per_token": dec_alone_ms, "measured": "decode of a batch alone on the chip" if alone else "timed region"},
     }
     out.update(extras)
     if world == 1 and not args.no_cpu_baseline:

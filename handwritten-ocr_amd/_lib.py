@@ -10,7 +10,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 9  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
+ABI_VERSION = 10  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
 
 P = C.c_void_p
 I = C.c_int
@@ -99,6 +99,12 @@ class DecWs(C.Structure):
                                   "q8s")]
 
 
+class Rows16Norm(C.Structure):
+    """hwocr_rows16_norm: the RMSNorm prologue of hwocr_gemm_rows16."""
+    _fields_ = [("h_in", P), ("h_out", P), ("ldh", I), ("slabs", P), ("nslab", I), ("slab_stride", L), ("ld_slab", I), ("norm_w", P),
+                ("eps", F), ("gemma", I)]
+
+
 class GenState(C.Structure):
     _fields_ = [(n, P) for n in ("cur_ids", "lens", "n_gen", "finished", "out_tokens", "rope_delta")] + [
         ("max_new", I), ("min_new", I), ("n_eos", I), ("pad_id", I), ("eos", I * 4), ("seen", P), ("seen_ld", I),
@@ -114,6 +120,7 @@ _HIP_SIGS = {
     "hwocr_rmsnorm_fp8": ([P, I, P, P, P, I, I, I, F, I, P], I),
     "hwocr_gemm_wide_fp8": ([P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P], I),
     "hwocr_gemm_skinny": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P], I),
+    "hwocr_gemm_rows16": ([P, I, P, P, I, I, I, I, I, I, C.POINTER(Rows16Norm), P], I),
     "hwocr_gemm_skinny_variant": ([I, I, I, I, I, I, C.c_char_p, I], I),
     "hwocr_attn_decode_variant": ([I, I, I, C.c_char_p, I], I),
     "hwocr_decode_gemm_plan": ([C.POINTER(Decoder), I, I, C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I), C.POINTER(I)], I),

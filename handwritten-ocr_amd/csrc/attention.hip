@@ -938,23 +938,37 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
   }
 }
 
+// One workgroup per (query head, read), one thread per output feature.  All <= 16 partial (m, l) pairs and output values of the
+// thread are loaded up front (indices clamped, never a branch around a load: the loads of a head's 16 splits are one round trip
+// to L2, not sixteen) and then combined in ascending split order — the arithmetic of the first form of this kernel, which walked
+// the splits in a loop of dependent loads from 6 workgroups and took 22 us of a 3-read decode layer's 70 (r03c profile).
 template <int DEC_HD>
-__global__ __launch_bounds__(256) void attn_decode_merge_kernel(DecodeArgs a) {
-  const int hk = blockIdx.x, b = blockIdx.y;
-  for (int idx = threadIdx.x; idx < a.G * DEC_HD; idx += 256) {
-    const int qq = idx / DEC_HD, d = idx % DEC_HD;
-    const long base = ((long)b * a.Hkv + hk) * a.nsplit * a.G;
-    float M = NEG_BIG;
-    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.part_ml[(base + s * a.G + qq) * 2]);
-    float L = 0.f, O = 0.f;
-    for (int s = 0; s < a.nsplit; ++s) {
-      const long e = base + s * a.G + qq;
-      const float f = exp2f(a.part_ml[e * 2] - M);
-      L += a.part_ml[e * 2 + 1] * f;
-      O += a.part_o[e * DEC_HD + d] * f;
-    }
-    a.out[((long)b * a.Hq + hk * a.G + qq) * DEC_HD + d] = f2bf(O / L);
+__global__ __launch_bounds__(DEC_HD) void attn_decode_merge_kernel(DecodeArgs a) {
+  const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const int hk = h / a.G, qq = h - hk * a.G;
+  const long base = ((long)b * a.Hkv + hk) * a.nsplit * a.G + qq;
+  float m[16], l[16], o[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const long e = base + (long)(s < a.nsplit ? s : 0) * a.G;
+    const f32x2 ml = *(const f32x2*)(a.part_ml + e * 2);
+    m[s] = ml[0];
+    l[s] = ml[1];
+    o[s] = a.part_o[e * DEC_HD + d];
   }
+  float M = NEG_BIG;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) M = s < a.nsplit ? fmaxf(M, m[s]) : M;
+  float L = 0.f, O = 0.f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    if (s < a.nsplit) {
+      const float f = exp2f(m[s] - M);
+      L += l[s] * f;
+      O += o[s] * f;
+    }
+  }
+  a.out[((long)b * a.Hq + h) * DEC_HD + d] = f2bf(O / L);
 }
 
 }  // namespace
@@ -1021,9 +1035,11 @@ extern "C" int hwocr_attn_varlen(const void* Q, const void* K, const void* VT, v
 namespace {
 int launch_attn_decode(const DecodeArgs& a, int nseq, int head_dim, hipStream_t stream) {
   const int Hkv = a.Hkv, nsplit = a.nsplit;
+  HWOCR_PLAN("attn_decode_kernel<%s,%d,%d>%s fused_qkv=%d nseq=%d Hq=%d Hkv=%d nsplit=%d nslab=%d", a.kv_tiled ? "tiled" : "rows",
+             (head_dim == 256 || nsplit > 1) ? 4 : 8, head_dim, nsplit > 1 ? "+merge" : "", a.slabs != nullptr, nseq, a.Hq, Hkv, nsplit, a.nslab);
   if (head_dim == 256) {  // 4 waves; a single pass when the caller asks for no split
     hipLaunchKernelGGL((attn_decode_kernel<false, 4, 256>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
-    if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<256>, dim3(Hkv, nseq), dim3(256), 0, stream, a);
+    if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<256>, dim3(a.Hq, nseq), dim3(256), 0, stream, a);
     return hwocr_launch_status();
   }
   if (nsplit == 1) {
@@ -1034,7 +1050,7 @@ int launch_attn_decode(const DecodeArgs& a, int nseq, int head_dim, hipStream_t 
   } else {
     hipLaunchKernelGGL((attn_decode_kernel<false, 4, 128>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
   }
-  if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<128>, dim3(Hkv, nseq), dim3(256), 0, stream, a);
+  if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<128>, dim3(a.Hq, nseq), dim3(128), 0, stream, a);
   return hwocr_launch_status();
 }
 bool attn_decode_args_ok(int nseq, int Hq, int Hkv, int nsplit, float* part_o, float* part_ml, long k_seq, long k_head,

@@ -1100,6 +1100,7 @@ extern "C" int hwocr_decode_qkv_finish(const float* slabs, int nslab, long slab_
                (const bf16*)cos_tab, (const bf16*)sin_tab, Hq, Hkv, k_seq, k_head, v_seq, v_head, v_row, kv_tiled,
                ctx, max_pos, status};
   const size_t lds = (size_t)(Hq + 2 * Hkv) * head_dim * 2;
+  HWOCR_PLAN("decode_qkv_finish_kernel<%d> nseq=%d Hq=%d Hkv=%d tiled=%d nslab=%d", head_dim, nseq, Hq, Hkv, kv_tiled, nslab);
   if (head_dim == 128) hipLaunchKernelGGL(decode_qkv_finish_kernel<128>, dim3(nseq), dim3(256), lds, stream, a);
   else hipLaunchKernelGGL(decode_qkv_finish_kernel<256>, dim3(nseq), dim3(256), lds, stream, a);
   return hwocr_launch_status();

@@ -17,6 +17,7 @@
 // Epilogues reproduce the points where the reference's bf16 modules materialise a tensor
 // (HF modeling_qwen2_vl.py:293-301 VisionMlp, :453-466 Qwen2MLP, :442-448 residual adds).
 #include "gemm_common.h"
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -329,8 +330,11 @@ struct WideProfile {
   int n = 0;   // launches recorded since the last enable
   std::vector<hipEvent_t> ev;      // 2 per launch, created on demand and reused: no cap, no silently dropped launch
   std::vector<double> flops;
-  // events of launch n (created if this is the first time n launches are recorded); false if HIP refuses
-  bool slot(hipEvent_t& a, hipEvent_t& b) {
+  std::mutex mu;                   // two host threads launch side by side when two batches are in flight (pipeline.LanePipeline)
+  // reserves the event pair of the next recorded launch (created if this is the first time that many launches are recorded) and
+  // books its FLOPs; false if HIP refuses
+  bool reserve(hipEvent_t& a, hipEvent_t& b, double fl) {
+    std::lock_guard<std::mutex> lock(mu);
     while ((int)ev.size() < 2 * (n + 1)) {
       hipEvent_t e;
       if (hipEventCreate(&e) != hipSuccess) return false;
@@ -339,6 +343,8 @@ struct WideProfile {
     if ((int)flops.size() < n + 1) flops.resize(n + 1);
     a = ev[2 * n];
     b = ev[2 * n + 1];
+    flops[n] = fl;
+    ++n;
     return true;
   }
 } g_prof;
@@ -376,15 +382,13 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
   WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, (const bf16*)res, (bf16*)out,
              M, N, K, ldx, ldw, ldo, ldres, (M + BM - 1) / BM, (N + BN - 1) / BN};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  const bool prof = g_prof.on == 1 && g_prof.slot(ev0, ev1);
+  const bool prof = g_prof.on == 1 && g_prof.reserve(ev0, ev1, 2.0 * M * (double)N * K);
   static const bool use256 = [] { const char* e = getenv("HWOCR_GEMM256"); return !e || atoi(e) != 0; }();
   if (use256 && M >= 1024 && N >= 256 && (ldo % 8) == 0 && (epi != EPI_RESIDUAL || (ldres % 8) == 0)) {
     if (prof) (void)hipEventRecord(ev0, stream);
     const int rc = hwocr_gemm_wide256(a, epi, stream);
     if (prof) {
       (void)hipEventRecord(ev1, stream);
-      g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
-      ++g_prof.n;
     }
     return rc;
   }
@@ -414,8 +418,6 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
   }
   if (prof) {
     (void)hipEventRecord(ev1, stream);
-    g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
-    ++g_prof.n;
   }
   return hwocr_launch_status();
 }
@@ -432,13 +434,11 @@ extern "C" int hwocr_gemm_wide_fp8(const void* X8, const float* xscale, const vo
   WideArgs a{(const bf16*)X8, (const bf16*)W8, (const bf16*)bias, (const bf16*)res, (bf16*)out,
              M, N, K, ldx, ldw, ldo, ldres, 0, 0, xscale, wscale};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  const bool prof = g_prof.on == 2 && g_prof.slot(ev0, ev1);
+  const bool prof = g_prof.on == 2 && g_prof.reserve(ev0, ev1, 2.0 * M * (double)N * K);
   if (prof) (void)hipEventRecord(ev0, stream);
   const int rc = hwocr_gemm_wide256_fp8(a, epi, stream);
   if (prof) {
     (void)hipEventRecord(ev1, stream);
-    g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
-    ++g_prof.n;
   }
   return rc;
 }
@@ -456,13 +456,11 @@ extern "C" int hwocr_gemm_vit_qkv(const void* X, const void* W, const void* bias
   const int N = 3 * sp->heads * sp->hd;
   WideArgs a{(const bf16*)X, (const bf16*)W, (const bf16*)bias, nullptr, nullptr, M, N, K, ldx, ldw, 0, 0, 0, 0, xscale, wscale, *sp};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  const bool prof = g_prof.on == (fp8 ? 2 : 1) && g_prof.slot(ev0, ev1);
+  const bool prof = g_prof.on == (fp8 ? 2 : 1) && g_prof.reserve(ev0, ev1, 2.0 * M * (double)N * K);
   if (prof) (void)hipEventRecord(ev0, stream);
   const int rc = hwocr_gemm_wide256_vit_qkv(a, fp8, stream);
   if (prof) {
     (void)hipEventRecord(ev1, stream);
-    g_prof.flops[g_prof.n] = 2.0 * M * (double)N * K;
-    ++g_prof.n;
   }
   return rc;
 }

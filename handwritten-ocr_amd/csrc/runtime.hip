@@ -303,6 +303,42 @@ extern "C" int hwocr_decode_gemm_plan(const hwocr_decoder* m, int nseq, int whic
   return HWOCR_OK;
 }
 
+// the token selection that ends a decode step: logits -> next token, stop flags, bookkeeping (all on the device)
+static int decode_select(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_gen_state* gs, int nseq, hipStream_t st) {
+  if (gs->do_sample) {
+    if (!gs->read_ids) return HWOCR_EINVAL;
+    return hwocr_sample_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished, gs->out_tokens,
+                                gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, gs->seen, gs->seen_ld, gs->rep_penalty,
+                                gs->temperature, gs->top_k, gs->top_p, gs->seed, gs->read_ids, nullptr, st);
+  }
+  return hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished,
+                              gs->out_tokens, gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, gs->seen, gs->seen_ld,
+                              gs->rep_penalty, st);
+}
+
+// <= 16 reads in flight and every layer GEMM with its bf16 fragment-tiled copy (no E4M3 decode weights): the 6-launch layer of
+// csrc/gemm_rows16.hip.  HWOCR_DECODE_ROWS16=0: the general path at every read count (A/B runs).
+static bool decode_takes_rows16(const hwocr_decoder* m, int nseq) {
+  static const bool on = [] { const char* e = getenv("HWOCR_DECODE_ROWS16"); return !e || atoi(e) != 0; }();
+  if (!on || nseq > 16 || m->hidden > 4096 || (m->hidden % 32) || (m->inter % 32) || ((m->Hq * m->head_dim) % 32)) return false;
+  for (int l = 0; l < m->layers; ++l) {
+    const hwocr_dec_layer& L = m->L[l];
+    if (!L.qkv_wt || !L.o_wt || !L.gate_up_wt || !L.down_wt || L.qkv8t || L.o8t || L.gate_up8t || L.down8t) return false;
+  }
+  return true;
+}
+// split-K of the down projection on that path: enough slices to put a workgroup on most CUs (N / 16 tiles each), at most 4 (the
+// consumer's norm prologue loads all slabs at once), slices of at least 16 k-steps
+static int rows16_down_split(const hwocr_decoder* m) {
+  const int tiles = m->hidden / 16, ksteps = m->inter / 32;
+  int s = 256 / tiles;
+  if (s > 4) s = 4;
+  if (s > ksteps / 16) s = ksteps / 16;
+  if (s < 1) s = 1;
+  const int per = (ksteps + s - 1) / s;  // every slice must own at least one k-step
+  return (ksteps + per - 1) / per;
+}
+
 extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
                                  const hwocr_gen_state* gs, int nseq, int attn_splits, hipStream_t st) {
   if (!m || !ws || !kv || !gs || nseq <= 0 || nseq > 256 || nseq > kv->nseq_max || attn_splits < 1 || attn_splits > 16 ||
@@ -315,6 +351,37 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   int s_qkv, s_o, s_d;
   decode_splits(m, nseq, s_qkv, s_o, s_d);
   CHECK(hwocr_embed_splice(gs->cur_ids, nullptr, m->embed, nullptr, ws->h, nseq, Hd, G ? m->embed_scale : 1.0f, st));
+  if (decode_takes_rows16(m, nseq)) {
+    // ---- at most 16 reads in flight: 6 launches per layer (csrc/gemm_rows16.hip).  The residual stream alternates between
+    // ws->h and ws->hn: a layer's QKV projection reads the previous layer's stream + the down projection's slabs in its norm
+    // prologue (every workgroup) and writes the updated stream to the OTHER buffer (one workgroup).
+    const int sd16 = rows16_down_split(m);
+    void* hbuf[2] = {ws->h, ws->hn};
+    int cur = 0;
+    for (int l = 0; l < m->layers; ++l) {
+      const hwocr_dec_layer& L = m->L[l];
+      bf16* Kc = B(kv->k) + l * k_layer;
+      bf16* Vc = B(kv->vt) + l * k_layer;
+      hwocr_rows16_norm n1{hbuf[cur], hbuf[cur ^ 1], Hd, l ? ws->slabs : nullptr, l ? sd16 : 0, (long)nseq * Hd, Hd, L.in_norm_w, m->eps, G};
+      cur ^= 1;
+      // the QKV projection leaves ONE fp32 slab (in ws->qkv: ws->slabs still holds the down projection's) for the attention launch
+      CHECK(hwocr_gemm_rows16(nullptr, 0, L.qkv_wt, ws->qkv, QW, nseq, QW, Hd, HWOCR_EPI_PARTIAL, 1, &n1, st));
+      CHECK(hwocr_attn_decode_qkv((const float*)ws->qkv, 1, (long)nseq * QW, L.qkv_b, Kc, Vc, gs->lens, gs->rope_delta, m->rope_cos,
+                                  m->rope_sin, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv, attn_splits, k_seq, k_head,
+                                  k_seq, k_head, kv->ctx, scale, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
+      CHECK(hwocr_gemm_rows16(ws->attn, OW, L.o_wt, hbuf[cur], Hd, nseq, Hd, OW, HWOCR_EPI_RESIDUAL, 1, nullptr, st));
+      hwocr_rows16_norm n2{hbuf[cur], nullptr, Hd, nullptr, 0, 0, 0, L.post_norm_w, m->eps, G};
+      CHECK(hwocr_gemm_rows16(nullptr, 0, L.gate_up_wt, ws->act, m->inter, nseq, 2 * m->inter, Hd, G ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, 1,
+                              &n2, st));
+      CHECK(hwocr_gemm_rows16(ws->act, m->inter, L.down_wt, ws->slabs, Hd, nseq, Hd, m->inter, HWOCR_EPI_PARTIAL, sd16, nullptr, st));
+    }
+    // last layer's slabs + residual -> final norm (the stream's last update is not needed afterwards, but the kernel does it in place)
+    CHECK(hwocr_add_rmsnorm(ws->slabs, sd16, (long)nseq * Hd, Hd, nullptr, hbuf[cur], Hd, m->final_norm_w, hbuf[cur ^ 1], Hd, nullptr, nseq,
+                            Hd, m->eps, G, st));
+    CHECK(decode_gemm(hbuf[cur ^ 1], m->lm_head, m->lm_head_t, m->lm_head8t.w, m->lm_head8t.scale, ws->logits, nseq, m->vocab, Hd, m->vocab,
+                      HWOCR_EPI_LINEAR, 1, st));
+    return decode_select(m, ws, gs, nseq, st);
+  }
   CHECK(hwocr_add_rmsnorm(nullptr, 0, 0, 0, nullptr, ws->h, Hd, m->L[0].in_norm_w, ws->hn, Hd, nullptr, nseq, Hd,
                           m->eps, G, st));
   for (int l = 0; l < m->layers; ++l) {
@@ -348,17 +415,7 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   }
   CHECK(decode_gemm(ws->hn, m->lm_head, m->lm_head_t, m->lm_head8t.w, m->lm_head8t.scale, ws->logits, nseq, m->vocab, Hd, m->vocab,
                     HWOCR_EPI_LINEAR, 1, st));
-  if (gs->do_sample) {
-    if (!gs->read_ids) return HWOCR_EINVAL;
-    CHECK(hwocr_sample_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished, gs->out_tokens,
-                               gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, gs->seen, gs->seen_ld, gs->rep_penalty,
-                               gs->temperature, gs->top_k, gs->top_p, gs->seed, gs->read_ids, nullptr, st));
-    return HWOCR_OK;
-  }
-  CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished,
-                             gs->out_tokens, gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, gs->seen, gs->seen_ld,
-                             gs->rep_penalty, st));
-  return HWOCR_OK;
+  return decode_select(m, ws, gs, nseq, st);
 }
 
 struct DecodeGraph {

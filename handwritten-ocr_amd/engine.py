@@ -371,35 +371,59 @@ def pick_attn_splits(reads: int, kv_heads: int) -> int:
 DECODE_GEMMS = ("qkv", "o", "gate_up", "down", "lm_head")
 
 
-def decode_plan(cfg: ModelConfig, reads: int, fp8: bool = False) -> dict:
-    """Kernel instances one decode step of `cfg` runs at `reads` reads in flight: {gemm name: (N, K, epi, splitk, variant)}
-    for the five GEMMs + "attn": variant.  fp8: the engine was built with fp8=True (E4M3 decode weights).  Host-only (asks the
-    library's own launch planner; nothing is launched)."""
+def decode_plan(cfg: ModelConfig, reads: int, fp8: bool = False, attn_splits: int = 0) -> dict:
+    """Kernel instances one decode step of `cfg` runs at `reads` reads in flight, as hwocr_decode_step itself lists them under plan
+    recording (hwocr_plan_begin; one decoder layer + the LM head + the token selection; nothing is launched): {gemm name: (N, K, epi,
+    splitk, variant)} for the five GEMMs, "attn": the attention instance, "launches": every line.  fp8: the engine was built with
+    E4M3 decode weights (fp8 + fp8_decode).  Host-only."""
+    import re
+
     lib = _lib.hip()
     layer = (_lib.DecLayer * 1)()
-    one = C.c_void_p(1)  # non-NULL: the engine always binds one tiled copy of every decode weight
+    one = C.c_void_p(64)  # non-NULL: the engine always binds one tiled copy of every decode weight
+    for f in ("in_norm_w", "qkv_w", "o_w", "post_norm_w", "gate_up_w", "down_w"):
+        setattr(layer[0], f, one)
+    if cfg.family != "paligemma":
+        layer[0].qkv_b = one
     if fp8:
         layer[0].qkv8t = layer[0].o8t = layer[0].gate_up8t = layer[0].down8t = one
+        layer[0].qkv8 = layer[0].o8 = layer[0].gate_up8 = layer[0].down8 = _lib.W8(w=one, scale=one)
     else:
         layer[0].qkv_wt = layer[0].o_wt = layer[0].gate_up_wt = layer[0].down_wt = one
-    dec = _lib.Decoder(layers=1, hidden=cfg.hidden, Hq=cfg.q_heads, Hkv=cfg.kv_heads, inter=cfg.inter, vocab=cfg.vocab,
-                       head_dim=cfg.head_dim, gemma=1 if cfg.family == "paligemma" else 0, L=layer)
+    dec = _lib.Decoder(layers=1, hidden=cfg.hidden, Hq=cfg.q_heads, Hkv=cfg.kv_heads, inter=cfg.inter, vocab=cfg.vocab, sec0=16, sec1=40,
+                       head_dim=cfg.head_dim, gemma=1 if cfg.family == "paligemma" else 0, eps=cfg.eps, embed_scale=1.0, embed=one,
+                       lm_head=one, final_norm_w=one, L=layer, rope_cos=one, rope_sin=one, max_pos=4096)
     if fp8:
         dec.lm_head8t = _lib.W8(w=one, scale=one)
     else:
         dec.lm_head_t = one
-    out = {}
-    buf = C.create_string_buffer(128)
-    for which, name in enumerate(DECODE_GEMMS):
-        N, K, epi, sk, tiled = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        _lib.check(lib.hwocr_decode_gemm_plan(C.byref(dec), reads, which, C.byref(N), C.byref(K), C.byref(epi), C.byref(sk),
-                                              C.byref(tiled)), "hwocr_decode_gemm_plan")
-        _lib.check(lib.hwocr_gemm_skinny_variant(reads, N.value, K.value, epi.value, sk.value, tiled.value, buf, len(buf)),
-                   "hwocr_gemm_skinny_variant")
-        out[name] = (N.value, K.value, epi.value, sk.value, buf.value.decode())
-    _lib.check(lib.hwocr_attn_decode_variant(pick_attn_splits(reads, cfg.kv_heads), cfg.head_dim, 1 if cfg.head_dim == 128 else 0,
-                                             buf, len(buf)), "hwocr_attn_decode_variant")
-    out["attn"] = buf.value.decode()
+    ws = _lib.DecWs(**{k: one for k in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "logits")})
+    kv = _lib.Kv(k=one, vt=one, nseq_max=max(reads, 1), ctx=2048, tiled=1 if cfg.head_dim == 128 else 0)
+    eos = (C.c_int * 4)(0, 0, 0, 0)
+    gs = _lib.GenState(cur_ids=one, lens=one, n_gen=one, finished=one, out_tokens=one, rope_delta=one, max_new=8, min_new=0, n_eos=1,
+                       pad_id=0, eos=eos, seen=None, seen_ld=0, rep_penalty=1.0, status=one, do_sample=0, temperature=1.0, top_k=0,
+                       top_p=1.0, seed=0, read_ids=one)
+    splits = attn_splits or pick_attn_splits(reads, cfg.kv_heads)
+    _lib.check(lib.hwocr_plan_begin(), "hwocr_plan_begin")
+    try:
+        rc = lib.hwocr_decode_step(C.byref(dec), C.byref(ws), C.byref(kv), C.byref(gs), reads, splits, None)
+    finally:
+        need = C.c_int()
+        lib.hwocr_plan_end(None, 0, C.byref(need))
+        buf = C.create_string_buffer(need.value)
+        lib.hwocr_plan_end(buf, len(buf), C.byref(need))
+    _lib.check(rc, "hwocr_decode_step (plan)")
+    lines = [l for l in buf.value.decode().split("\n") if l]
+    gemms = [l for l in lines if l.startswith("gemm_")]
+    if len(gemms) != len(DECODE_GEMMS):
+        raise _lib.HwocrError(f"a decode step of one layer lists {len(gemms)} GEMM launches, expected {len(DECODE_GEMMS)}: {lines}")
+    out = {"launches": lines}
+    for name, line in zip(DECODE_GEMMS, gemms):
+        variant, geom = line.split(" rows=", 1)
+        f = dict(re.findall(r"(\w+)=(\d+)", "rows=" + geom))
+        out[name] = (int(f["N"]), int(f["K"]), int(re.search(r"epi=(\d+)", variant).group(1)), int(f["splitk"]), variant)
+    attn = [l for l in lines if l.startswith("attn_decode_kernel")]
+    out["attn"] = attn[0].split(" ", 1)[0] if attn else ""
     return out
 
 
@@ -852,6 +876,18 @@ class ReadEngine:
     def close(self) -> None:
         self._drop_graphs()
 
+    def lane(self) -> "ReadEngine":
+        """A second set of read slots over the SAME weights: own KV cache, generation state, workspaces and captured graphs; the
+        bound weight tensors and the model structs (read-only at run time) are shared.  Two lanes driven from two host threads on
+        two HIP streams let one batch's tower + prefill (matrix pipes) run beside another batch's decode (HBM): pipeline.LanePipeline."""
+        import copy
+
+        other = copy.copy(self)
+        other._graphs, other.timings, other._keep_tmp = {}, {}, None
+        other._alloc_state()
+        other._vit_layout = None
+        return other
+
     # ------------------------------------------------------------------------------------------ vision tower
     def encode_pages(self, pages: list[np.ndarray]) -> tuple[torch.Tensor, list[tuple[int, int, int]], list[np.ndarray]]:
         """uint8 [H, W, 3] pages already at tower resolution -> (embedding buffer [rows][hidden], grids, and for each
@@ -949,7 +985,7 @@ class ReadEngine:
 
     def generate(self, pages: list[np.ndarray], prompts: list[np.ndarray], max_new: int, min_new: int = 0,
                  forced: np.ndarray | None = None, return_logits: bool = False, use_graph: bool = True,
-                 repetition_penalty: float | None = None, sample: dict | None = None, read_base: int = 0):
+                 repetition_penalty: float | None = None, sample: dict | None = None, read_base: int = 0, hooks=None):
         """Reads: greedy, or drawn (cfg.do_sample from generation_config.json, or `sample` = dict(temperature, top_k, top_p[, seed])
         for this call; `sample={}` forces greedy): read i draws from the RNG stream of read number read_base + i, whichever slot or
         batch it is decoded in.  pages[i]: uint8 [H, W, 3] at tower resolution; prompts[i]: int32 token ids containing one run
@@ -970,6 +1006,8 @@ class ReadEngine:
                 ev.record()
                 marks.append((name, ev))
 
+        if hooks is not None:   # pipeline.LanePipeline: this batch's tower waits (on the device) for the previous batch's prefill
+            hooks.tower_begin()
         mark("start")
         emb, grids, tok_rows = self.encode_pages(pages)
         mark("vision")
@@ -1047,6 +1085,8 @@ class ReadEngine:
                 first_logits.append(self._bufs["logits"][:n].clone())
             chunk_keep.append((last, pos_chunk))  # index tensors stay alive until the stream has consumed them (no host sync per chunk)
         mark("prefill")
+        if hooks is not None:   # ... and its decode for the previous batch's decode
+            hooks.prefill_end()
         if return_logits:
             step_logits.append(torch.cat(first_logits, dim=0))
         def feed(col):  # teacher forcing: the fed token replaces the chosen one (the select kernel adds what it was fed
@@ -1084,6 +1124,8 @@ class ReadEngine:
                 if forced is not None and i + 1 < max_new:
                     feed(i + 1)
         mark("decode")
+        if hooks is not None:
+            hooks.decode_end()
         torch.cuda.current_stream().synchronize()
         self._check_status()
         if marks:

@@ -38,7 +38,7 @@ typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
 #define HWOCR_EPI_GELU_TANH 6 /* nn.GELU(approximate="tanh"): SigLIP MLP (HF siglip/modeling_siglip.py:310-322) */
 #define HWOCR_EPI_GEGLU 7     /* SWIGLU's interleaved tile pairs with the tanh GELU as gate: Gemma MLP (HF gemma/modeling_gemma.py:84-97) */
 
-#define HWOCR_ABI_VERSION 9 /* bumped whenever a signature or struct layout below changes */
+#define HWOCR_ABI_VERSION 10 /* bumped whenever a signature or struct layout below changes */
 int hwocr_abi_version(void);
 /* text of the most recent launch failure in this process ("" if none): launcher name + HIP error */
 const char* hwocr_last_error(void);
@@ -81,6 +81,24 @@ int hwocr_gemm_skinny(const void* X, const void* W, const void* bias, void* out,
 int hwocr_tile_weights_fp8(const void* src, void* dst, int N, int K, int ldw, hwocr_stream_t stream);
 int hwocr_gemm_skinny_w8(const void* X, const void* W8t, const float* wscale, const void* bias, void* out, int Bsz, int N, int K,
                          int ldx, int ldo, int epi, int splitk, hwocr_stream_t stream);
+
+/* The decode GEMMs with AT MOST 16 reads in flight (one page = 3 reads; the tail of a continuous batch): csrc/gemm_rows16.hip.
+ * out[Bsz <= 16][N] = x[Bsz][K] . Wt^T over the fragment-tiled bf16 weights (hwocr_tile_weights), no K-tile ring: the waves of a
+ * workgroup split a tile's K range, stream their slices HBM -> registers and sum them through LDS in ascending K order.
+ *   norm == NULL: x = X (bf16 rows, ldx).   norm != NULL (K <= 4096): the RMSNorm in front of the projection is the kernel's
+ *   prologue — x = RMSNorm(h'), h' = bf16(bf16(sum of norm->nslab <= 4 fp32 slabs) + h_in) (nslab == 0: h' = h_in), with the
+ *   reference's rounding chain (hwocr_add_rmsnorm's arithmetic; gemma: (1 + w) in fp32); h' is stored once to h_out (may be NULL;
+ *   must NOT alias h_in: every workgroup reads h_in).
+ *   epi: HWOCR_EPI_PARTIAL (fp32 slabs [splitk][Bsz][ldo], the only one that takes splitk > 1), HWOCR_EPI_RESIDUAL (out is the
+ *   bf16 residual stream, updated in place: out <- bf16(bf16(acc) + out)), HWOCR_EPI_SWIGLU / _GEGLU (interleaved gate / up tiles,
+ *   out [Bsz][N/2]), HWOCR_EPI_LINEAR (bf16, no bias).  N % 16 == 0 (gated: % 32), K % 32 == 0. */
+typedef struct hwocr_rows16_norm {
+  const void* h_in; void* h_out; int ldh;
+  const float* slabs; int nslab; long slab_stride; int ld_slab;
+  const void* norm_w; float eps; int gemma;
+} hwocr_rows16_norm;
+int hwocr_gemm_rows16(const void* X, int ldx, const void* Wt, void* out, int ldo, int Bsz, int N, int K, int epi, int splitk,
+                      const hwocr_rows16_norm* norm, hwocr_stream_t stream);
 
 /* Name of the kernel instance the call hwocr_gemm_skinny(Bsz, N, K, epi, splitk, w_tiled) would launch (ldx = ldw = K,
  * ldo = N; w_tiled == 2: hwocr_gemm_skinny_w8), written NUL-terminated into name[name_len]; launches nothing and needs no device.  The decode GEMMs pick among

@@ -39,7 +39,8 @@ def test_abi_version_and_structs():
 
     pairs = {"hwocr_vit": _lib.Vit, "hwocr_vit_block": _lib.VitBlock, "hwocr_vit_layout": _lib.VitLayout,
              "hwocr_vit_ws": _lib.VitWs, "hwocr_decoder": _lib.Decoder, "hwocr_dec_layer": _lib.DecLayer,
-             "hwocr_gen_state": _lib.GenState, "hwocr_kv": _lib.Kv, "hwocr_dec_ws": _lib.DecWs, "hwocr_w8": _lib.W8}
+             "hwocr_gen_state": _lib.GenState, "hwocr_kv": _lib.Kv, "hwocr_dec_ws": _lib.DecWs, "hwocr_w8": _lib.W8,
+             "hwocr_rows16_norm": _lib.Rows16Norm, "hwocr_vit_split": _lib.VitSplit}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hwocr.h"', "int main(void) {"]
     for cname, ct in pairs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

@@ -12,7 +12,7 @@ from handwritten_ocr_amd import _lib, engine
 from tests import test_ops_gpu as ops
 
 PRESETS = ("qwen2-vl-2b", "qwen2.5-vl-7b", "qwen2.5-vl-3b", "paligemma-3b", "small", "tiny", "tiny25", "tinypg")
-READS = (1, 3, 126, 252)
+READS = (1, 3, 16, 17, 126, 252)
 
 
 def _gemm_variant(B, N, K, epi, splitk, w_tiled=1):
@@ -27,8 +27,26 @@ def _attn_variant(nsplit, hd, tiled):
     return buf.value.decode()
 
 
+def _rows16_variant(B, N, K, epi, splitk, norm, nslab, gemma):
+    """The instance + path class hwocr_gemm_rows16 notes for a call (plan recording: nothing is launched)."""
+    lib = _lib.hip()
+    one = C.c_void_p(64)
+    blk = _lib.Rows16Norm(h_in=one, h_out=one, ldh=K, slabs=one if nslab else None, nslab=nslab, slab_stride=B * K, ld_slab=K, norm_w=one,
+                          eps=1e-6, gemma=gemma)
+    assert lib.hwocr_plan_begin() == 0
+    rc = lib.hwocr_gemm_rows16(None if norm else one, 0 if norm else K, one, one, N // 2 if epi in (4, 7) else N, B, N, K, epi, splitk,
+                               C.byref(blk) if norm else None, None)
+    need = C.c_int()
+    lib.hwocr_plan_end(None, 0, C.byref(need))
+    buf = C.create_string_buffer(need.value)
+    lib.hwocr_plan_end(buf, len(buf), C.byref(need))
+    assert rc == 0
+    return buf.value.decode().split(" rows=")[0]
+
+
 def _covered():
     gemm = {_gemm_variant(*c) for c in ops.DECODE_GEMM_CASES}
+    gemm |= {_rows16_variant(*c) for c in ops.ROWS16_CASES}
     # the older operator cases: (B, N, K) x {linear, partial} and the gated ones at N = 3584
     for B in (1, 7, 16, 48, 96, 128, 190, 256):
         for N, K in ((96, 64), (2048, 1536), (1536, 2304)):

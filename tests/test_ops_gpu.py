@@ -219,6 +219,8 @@ DECODE_GEMM_SHAPES = {
     3: [(2048, 1536, 5, 4), (17920, 1536, 4, 1), (1536, 8960, 5, 12), (151936, 1536, 0, 1), (32768, 2048, 7, 1)],
     130: [(2048, 1536, 5, 4), (17920, 1536, 4, 1), (1536, 8960, 5, 8), (151936, 1536, 0, 1), (37888, 3584, 4, 1)],
     256: [(17920, 1536, 4, 1), (1536, 8960, 5, 8), (151936, 1536, 0, 1), (32768, 2048, 7, 1)],
+    # 17..32 reads (the two-row-tile instance; <= 16 reads take csrc/gemm_rows16.hip: ROWS16_CASES): the tail of a continuous batch
+    24: [(2048, 1536, 5, 4), (17920, 1536, 4, 1), (1536, 8960, 5, 12), (151936, 1536, 0, 1), (32768, 2048, 7, 1), (32768, 768, 0, 1)],
 }
 DECODE_GEMM_CASES = [(B,) + shape for B, shapes in DECODE_GEMM_SHAPES.items() for shape in shapes]
 
@@ -254,6 +256,96 @@ def test_gemm_skinny_decode_shapes(B, N, K, epi, splitk):
 
 
 # ------------------------------------------------------------------------------------------------ attention
+# ---- the decode GEMMs with at most 16 reads in flight (csrc/gemm_rows16.hip): (rows, N, K, epi, splitk, norm prologue?, slabs summed
+# by the prologue, gemma) as hwocr_decode_step issues them per preset — qkv (norm, the previous layer's down slabs), o (residual in
+# place), gate/up (norm, gated), down (split-K slabs) — at 1 / 3 / 7 / 16 rows; tests/test_decode_variants.py holds every preset's
+# plan against the classes of this list
+ROWS16_CASES = [
+    # Qwen2-VL-2B
+    (3, 2048, 1536, 5, 1, True, 0, 0), (3, 2048, 1536, 5, 1, True, 2, 0), (3, 1536, 1536, 1, 1, False, 0, 0),
+    (3, 17920, 1536, 4, 1, True, 0, 0), (3, 1536, 8960, 5, 2, False, 0, 0),
+    (1, 2048, 1536, 5, 1, True, 2, 0), (16, 2048, 1536, 5, 1, True, 2, 0), (7, 17920, 1536, 4, 1, True, 0, 0), (16, 1536, 8960, 5, 2, False, 0, 0),
+    (16, 1536, 1536, 1, 1, False, 0, 0), (1, 17920, 1536, 4, 1, True, 0, 0),
+    # Qwen2.5-VL-7B / -3B
+    (3, 4608, 3584, 5, 1, True, 1, 0), (3, 3584, 3584, 1, 1, False, 0, 0), (3, 37888, 3584, 4, 1, True, 0, 0), (3, 3584, 18944, 5, 1, False, 0, 0),
+    (3, 2560, 2048, 5, 1, True, 2, 0), (3, 22016, 2048, 4, 1, True, 0, 0), (3, 2048, 11008, 5, 2, False, 0, 0),
+    # PaliGemma-3B (Gemma norm, GeGLU)
+    (3, 2560, 2048, 5, 1, True, 2, 1), (3, 2048, 2048, 1, 1, False, 0, 0), (3, 32768, 2048, 7, 1, True, 0, 1), (3, 2048, 16384, 5, 2, False, 0, 0),
+    # `small` preset (4 slabs: the most a prologue sums) and the tiny golden models (K = 256: fewer k-steps than K slices)
+    (3, 1280, 768, 5, 1, True, 4, 0), (3, 768, 768, 1, 1, False, 0, 0), (3, 6144, 768, 4, 1, True, 0, 0), (3, 768, 3072, 5, 4, False, 0, 0),
+    (2, 512, 256, 5, 1, True, 1, 0), (2, 256, 256, 1, 1, False, 0, 0), (2, 512, 256, 4, 1, True, 0, 0), (2, 256, 256, 5, 1, False, 0, 0),
+    (2, 768, 256, 5, 1, True, 1, 1), (2, 256, 512, 1, 1, False, 0, 0), (2, 1024, 256, 7, 1, True, 0, 1), (2, 256, 512, 5, 1, False, 0, 0),
+]
+
+
+def _rows16_norm_ref(h, slabs, w, gemma, eps=1e-6):
+    """(h', x): the residual update and the normalised GEMM input of the prologue, reference's rounding chain."""
+    hf = h.float()
+    if slabs is not None:
+        y = torch.zeros_like(hf)
+        for sl in slabs:           # ascending slab order, as the kernel
+            y = y + sl
+        hf = rbf(rbf(y) + hf)
+    xhat = hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + eps)
+    x = rbf(xhat * (1.0 + w.float())) if gemma else rbf(w.float() * rbf(xhat))
+    return hf, x
+
+
+@pytest.mark.parametrize("B,N,K,epi,splitk,norm,nslab,gemma", ROWS16_CASES)
+def test_gemm_rows16(B, N, K, epi, splitk, norm, nslab, gemma):
+    """hwocr_gemm_rows16 against the fp32 product of the same bf16 operands, with the RMSNorm prologue (residual update written back
+    once, bit-exact; normalised rows as hwocr_add_rmsnorm) and every epilogue the <= 16-read decode layer uses."""
+    import ctypes as C
+
+    from handwritten_ocr_amd import _lib
+    w = randbf(N, K, scale=K ** -0.5, seed=91)
+    wk = _tiled(w)
+    if norm:
+        h = randbf(B, K, scale=2.0, seed=92)
+        nw = randbf(K, scale=0.3, seed=93) + (0.0 if gemma else 1.0)
+        slabs = torch.randn(max(nslab, 1), B, K, device=DEV) if nslab else None
+        h_out = torch.full((B, K), float("nan"), dtype=torch.bfloat16, device=DEV)
+        blk = _lib.Rows16Norm(h_in=p(h), h_out=p(h_out), ldh=K, slabs=p(slabs) if nslab else None, nslab=nslab, slab_stride=B * K, ld_slab=K,
+                              norm_w=p(nw), eps=1e-6, gemma=gemma)
+        hp, x = _rows16_norm_ref(h, slabs[:nslab] if nslab else None, nw, gemma)
+        nref, xptr, ldx = C.byref(blk), None, 0
+    else:
+        xb = randbf(B, K, seed=94)
+        x, nref, xptr, ldx = xb.float(), None, p(xb), K
+    acc = x @ w.float().t()
+    # a normalised element that rounds to the neighbouring bf16 (the row statistic is summed in another order) moves a sum of K terms
+    # by |w| ulp(x): far below the output's own rounding; the fp32 slabs get an absolute allowance for it
+    if epi == 5:
+        out = torch.full((splitk, B, N), float("nan"), dtype=torch.float32, device=DEV)
+        assert lib().hwocr_gemm_rows16(xptr, ldx, p(wk), p(out), N, B, N, K, 5, splitk, nref, st()) == 0
+        sync()
+        assert torch.isfinite(out).all(), "a slab element was left unwritten"
+        got = out.sum(0)
+        assert torch.allclose(got, acc, rtol=1e-4, atol=6e-3 if norm else 2e-3), f"partial splitk={splitk}: {(got - acc).abs().max()}"
+    elif epi == 1:
+        res = randbf(B, N, seed=95)
+        out = res.clone()
+        assert lib().hwocr_gemm_rows16(xptr, ldx, p(wk), p(out), N, B, N, K, 1, 1, nref, st()) == 0
+        sync()
+        assert_close_bf16(out, rbf(acc) + res.float(), ulps=2.0, atol=2e-3, what="rows16 residual", mag=acc.abs() + res.float().abs())
+    else:
+        out = torch.full((B, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+        assert lib().hwocr_gemm_rows16(xptr, ldx, p(wk), p(out), N // 2, B, N, K, epi, 1, nref, st()) == 0
+        sync()
+        want = _swiglu_ref(acc, geglu=(epi == 7))
+        gate = rbf(acc.view(B, N // 32, 2, 16)[:, :, 0, :]).reshape(B, N // 2)
+        assert_close_bf16(out, want, ulps=3.0, atol=3e-3, what="rows16 gated", mag=want.abs() * (1.0 + gate.abs()))
+    if norm:
+        assert torch.equal(h_out.float(), hp), "the residual update written back by the prologue"
+
+
+def test_gemm_rows16_rejects_what_it_cannot_run():
+    x = randbf(16, 64)
+    assert lib().hwocr_gemm_rows16(p(x), 64, p(x), p(x), 64, 17, 64, 64, 0, 1, None, st()) == 1    # more than 16 rows
+    assert lib().hwocr_gemm_rows16(p(x), 64, p(x), p(x), 64, 4, 64, 64, 1, 2, None, st()) == 1     # split-K without PARTIAL
+    assert lib().hwocr_gemm_rows16(None, 0, p(x), p(x), 64, 4, 64, 64, 0, 1, None, st()) == 1      # neither rows nor a norm block
+
+
 def _sdpa_ref(q, k, v, causal, scale):
     # q [Hq, L, d], k/v [Hkv, L, d] (fp32); returns [L, Hq, d]
     Hq, Lq, d = q.shape
@@ -1114,7 +1206,7 @@ def test_tile_weights_fp8_layout():
 # shape under --fp8, the tiny golden model; (N, K, epi, splitk) from engine.decode_plan(..., fp8=True)
 DECODE_GEMM_SHAPES_W8 = {
     3: [(2560, 2048, 5, 5), (32768, 2048, 7, 1), (2048, 16384, 5, 12), (257216, 2048, 0, 1), (17920, 1536, 4, 1), (512, 256, 0, 1)],
-    24: [(2560, 2048, 5, 5), (32768, 2048, 7, 1), (1024, 256, 7, 1)],
+    24: [(2560, 2048, 5, 5), (32768, 2048, 7, 1), (1024, 256, 7, 1), (17920, 1536, 4, 1), (257216, 2048, 0, 1)],
     40: [(2048, 2048, 5, 5), (32768, 2048, 7, 1)],
     126: [(2560, 2048, 5, 5), (2048, 2048, 5, 5), (32768, 2048, 7, 1), (2048, 16384, 5, 12), (257216, 2048, 0, 1), (17920, 1536, 4, 1)],
     252: [(2560, 2048, 5, 4), (2048, 2048, 5, 4), (32768, 2048, 7, 1), (2048, 16384, 5, 8), (257216, 2048, 0, 1),
