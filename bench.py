@@ -360,8 +360,11 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip the with_upload / host_preprocess_path / single-page legs")
     ap.add_argument("--profile-steps", type=int, default=0, help="(ignored: every wide-GEMM launch of the timed region carries HIP events)")
     ap.add_argument("--lanes", type=int, default=2,
-                    help="batches in flight on the GPU: 2 = batch k's decode beside batch k+1's tower + prefill on two HIP streams "
-                         "(pipeline.LanePipeline); 1 = one batch at a time (the schedule of rounds 1-2)")
+                    help="batches in flight on the GPU, one engine lane, host thread and HIP stream each (pipeline.LanePipeline); "
+                         "1 = one batch at a time (the schedule of rounds 1-2)")
+    ap.add_argument("--lane-order", default="lockstep", choices=("lockstep", "alternate"),
+                    help="lockstep: the lanes start together (tower beside tower, decode beside decode); alternate: batch k's decode "
+                         "beside batch k+1's tower + prefill, enforced by events (measured slower: pipeline.py)")
     ap.add_argument("--fp8", action="store_true",
                     help="E4M3 wide GEMMs for the vision tower and the prefill (BASELINE config 4; not the headline configuration)")
     args = ap.parse_args()
@@ -398,7 +401,7 @@ def main() -> None:
         del sd  # (else kept: the CPU baseline runs the oracle on a host copy of these very weights; the engine aliases them)
     eng.collect_timings = True
     tok = tokenizer.ByteTokenizer(cfg, fold_unknown=True)
-    pipe = pipeline.LanePipeline(eng, lanes=max(1, args.lanes))
+    pipe = pipeline.LanePipeline(eng, lanes=max(1, args.lanes), order=args.lane_order)
     for e in pipe.engines:
         e.collect_timings = True
     sps = {id(e): gpupre.StrategyPages(dev) for e in pipe.engines}   # (a lane's own scratch: two host threads preprocess side by side)
@@ -574,8 +577,8 @@ def main() -> None:
                    "image_tokens": int((prompts[0] == cfg.image_token_id).sum()), "new_tokens": args.new_tokens,
                    "single_page_latency_ms": extras.get("single_page", {}).get("latency_ms"),
                    "lanes": len(pipe.engines),
-                   "schedule": ("two batches in flight per GPU: batch k's decode beside batch k+1's tower + prefill on two HIP streams "
-                                "(pipeline.LanePipeline; same tokens as one batch at a time)" if len(pipe.engines) > 1 else
+                   "schedule": (f"{len(pipe.engines)} batches in flight per GPU, one engine lane + host thread + HIP stream each, order "
+                                f"'{pipe.order}' (pipeline.LanePipeline; same tokens as one batch at a time)" if len(pipe.engines) > 1 else
                                 "one batch at a time: tower, prefill, decode back to back on one stream"),
                    "parallelism": f"replicas x{world}, pages sharded, RCCL gather of token streams"},
         "roofline": {"bound": "mfma",

@@ -280,29 +280,6 @@ static void decode_splits(const hwocr_decoder* m, int nseq, int& s_qkv, int& s_o
   s_d = stream ? pick_splitk_stream(m->inter, Hd, nseq) : pick_splitk(m->inter, Hd, 400);
 }
 
-// The GEMM calls hwocr_decode_step makes for layer 0 (every layer has the same shapes) and for the LM head, as arguments of
-// hwocr_gemm_skinny: which = 0 qkv, 1 o, 2 gate/up, 3 down, 4 LM head.  For the parity tests: "is there an oracle case for
-// the kernel instance the bench's decode step runs?" (answered together with hwocr_gemm_skinny_variant).
-extern "C" int hwocr_decode_gemm_plan(const hwocr_decoder* m, int nseq, int which, int* N, int* K, int* epi, int* splitk,
-                                      int* w_tiled) {
-  if (!m || !m->L || nseq <= 0 || nseq > 256 || which < 0 || which > 4 || !N || !K || !epi || !splitk || !w_tiled)
-    return HWOCR_EINVAL;
-  const int HD = m->head_dim, Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
-  int s_qkv, s_o, s_d;
-  decode_splits(m, nseq, s_qkv, s_o, s_d);
-  const hwocr_dec_layer& L = m->L[0];
-  switch (which) {
-    case 0: *N = QW, *K = Hd, *epi = HWOCR_EPI_PARTIAL, *splitk = s_qkv, *w_tiled = L.qkv8t ? 2 : L.qkv_wt != nullptr; break;
-    case 1: *N = Hd, *K = OW, *epi = HWOCR_EPI_PARTIAL, *splitk = s_o, *w_tiled = L.o8t ? 2 : L.o_wt != nullptr; break;
-    case 2: *N = 2 * m->inter, *K = Hd, *epi = m->gemma ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, *splitk = 1,
-            *w_tiled = L.gate_up8t ? 2 : L.gate_up_wt != nullptr; break;
-    case 3: *N = Hd, *K = m->inter, *epi = HWOCR_EPI_PARTIAL, *splitk = s_d, *w_tiled = L.down8t ? 2 : L.down_wt != nullptr; break;
-    default: *N = m->vocab, *K = Hd, *epi = HWOCR_EPI_LINEAR, *splitk = 1,
-             *w_tiled = m->lm_head8t.w ? 2 : m->lm_head_t != nullptr; break;
-  }
-  return HWOCR_OK;
-}
-
 // the token selection that ends a decode step: logits -> next token, stop flags, bookkeeping (all on the device)
 static int decode_select(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_gen_state* gs, int nseq, hipStream_t st) {
   if (gs->do_sample) {

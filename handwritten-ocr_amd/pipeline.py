@@ -1,19 +1,27 @@
-"""Two batches in flight on one GPU: batch k's decode (HBM / latency bound, 37 % of a step) beside batch k+1's vision tower + prefill
-(matrix-pipe bound, 63 %).
+"""Several batches in flight on one GPU: one `ReadEngine` lane per batch, each driven by its own host thread on its own HIP stream.
 
 The reference runs one read at a time (ocr_agent/nodes.py:86-110) and `ReadEngine.generate` one BATCH at a time: tower, prefill,
-then 511 decode steps, on one stream.  The two halves stress different parts of the chip, and run on two HIP streams they take less
-than their sum (tools/bench_overlap.py on the MI355X: 14.33 -> 15.35 pages/s, identical tokens).  `LanePipeline` is that schedule
-made explicit:
+then 511 decode steps, ~200 dependent launches each, on one stream.  A dependent chain leaves the chip partly idle (a decode step
+alternates HBM-bound attention launches with latency-bound GEMM launches; every launch has a ramp and a tail), and a second,
+independent chain fills those holes.  Measured on the MI355X (tools/bench_overlap.py, Qwen2-VL-2B shape, 84 pages x 3 reads x 512
+tokens per batch, tokens identical to the serial schedule in every arm; profiles/r03f_overlap_*.json):
 
-  * `lanes` ReadEngines over the same weights (`ReadEngine.lane()`: own KV cache / state / workspaces), each driven by its own host
-    thread on its own stream; job k runs on lane k % lanes;
-  * device-side ordering by events, so that at most ONE tower + prefill phase and ONE decode phase are in flight and they belong to
-    consecutive batches:  tower(k) waits for prefill(k-1) to finish, decode(k) for decode(k-1)  (`ReadEngine.generate(hooks=…)`);
-  * everything after a batch's decode (token gather, detokenise, compare / merge on the host) runs in that batch's thread while
-    the other lane's kernels keep the GPU busy.
+    one batch at a time                                   14.39 pages/s
+    2 lanes started together (phases in lockstep)         15.24   (+5.9 %: decode || decode 3764 ms for two batches against 2 x 2160,
+                                                                   tower || tower 5593 against 2 x 2835, prefill 1655 against 2 x 843)
+    2 lanes, second half a step late (decode || tower)    15.37   (+6.8 %) - but +0.2 % at a third of a step: phase-sensitive
+    2 lanes, strict alternation enforced by events        14.69   (+2.9 %: a decode chain beside a tower takes 2.8 x as long - its short
+                                                                   launches queue behind 0.5-ms persistent GEMMs - and paces the pipeline)
+    3 lanes                                               15.27-15.43
 
-Results are those of the sequential schedule bit for bit: a lane is an ordinary engine and batches never share state.
+`LanePipeline(order="lockstep")` (the default) is the second row made the rule: the lanes start together and, doing equal work, stay
+in step; nothing orders them on the device.  `order="alternate"` is the fourth row (kept selectable: it is the schedule VERDICT r2
+asked to be measured): tower(k) waits for prefill(k-1), decode(k) for decode(k-1), by HIP events (`ReadEngine.generate(hooks=...)`).
+Either way everything after a batch's decode (token gather, detokenise, compare / merge on the host) runs in that batch's thread,
+and `hooks.ordered()` serialises what all ranks of a multi-GPU run must issue in the same order (the RCCL gather).
+
+Results are those of the serial schedule bit for bit: a lane is an ordinary engine over the same weights (`ReadEngine.lane()`: own
+KV cache / state / workspaces) and batches never share state.
 """
 from __future__ import annotations
 
@@ -29,7 +37,7 @@ class _JobHooks:
         self.pipe, self.k = pipe, k
 
     def _after(self, recorded: dict, events: dict) -> None:
-        if self.k == 0:
+        if self.k == 0 or self.pipe.order != "alternate":
             return
         recorded[self.k - 1].wait()                       # host: the previous job has put its event into its stream
         torch.cuda.current_stream().wait_event(events[self.k - 1])
@@ -38,6 +46,8 @@ class _JobHooks:
         self._after(self.pipe._prefill_recorded, self.pipe._prefill_done)
 
     def prefill_end(self) -> None:
+        if self.pipe.order != "alternate":
+            return
         ev = torch.cuda.Event()
         ev.record()
         self.pipe._prefill_done[self.k] = ev
@@ -45,6 +55,8 @@ class _JobHooks:
         self._after(self.pipe._decode_recorded, self.pipe._decode_done)
 
     def decode_end(self) -> None:
+        if self.pipe.order != "alternate":
+            return
         ev = torch.cuda.Event()
         ev.record()
         self.pipe._decode_done[self.k] = ev
@@ -72,9 +84,12 @@ class _JobHooks:
 
 
 class LanePipeline:
-    def __init__(self, engine, lanes: int = 2):
+    def __init__(self, engine, lanes: int = 2, order: str = "lockstep"):
         if lanes < 1:
             raise ValueError("lanes must be >= 1")
+        if order not in ("lockstep", "alternate"):
+            raise ValueError("order must be 'lockstep' or 'alternate'")
+        self.order = order
         self.engines = [engine] + [engine.lane() for _ in range(lanes - 1)]
         self.device = engine.dev
         self.streams = [torch.cuda.Stream(device=self.device) for _ in self.engines]

@@ -342,11 +342,6 @@ int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv
 int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv, const hwocr_gen_state* st,
                       int nseq, int attn_splits, hwocr_stream_t stream);
 
-/* The GEMM calls one hwocr_decode_step makes (layer 0; every layer has the same shapes), as arguments of hwocr_gemm_skinny:
- * which = 0 qkv, 1 o, 2 gate/up, 3 down, 4 LM head; *w_tiled = 0 row-major, 1 fragment-tiled bf16, 2 byte-tiled E4M3 (hwocr_gemm_skinny_w8).
- * Only m's dimensions and the NULL-ness of the tiled weight pointers of m->L[0] / m->lm_head_t / m->lm_head8t are read.  Launches nothing. */
-int hwocr_decode_gemm_plan(const hwocr_decoder* m, int nseq, int which, int* N, int* K, int* epi, int* splitk, int* w_tiled);
-
 /* Plan recording: between hwocr_plan_begin() and hwocr_plan_end() every launcher of this library called on the SAME thread checks
  * its arguments as usual, records one text line "<kernel instance> <geometry>" and returns HWOCR_OK without touching the device
  * (pointers are never dereferenced on the host either, apart from the model / layout structs).  hwocr_vit_forward / hwocr_prefill /

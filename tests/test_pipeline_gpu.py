@@ -32,8 +32,10 @@ def setup():
     eng.close()
 
 
-def test_two_lanes_return_what_one_batch_at_a_time_returns(setup):
+@pytest.mark.parametrize("order", ["lockstep", "alternate"])
+def test_two_lanes_return_what_one_batch_at_a_time_returns(setup, order):
     eng, pipe, batches = setup
+    pipe.order = order   # lockstep: nothing orders the lanes on the device; alternate: tower(k) after prefill(k-1), decode(k) after decode(k-1)
     n = 24
     want = [eng.generate(p, q, max_new=n, min_new=n) for p, q in batches]
     jobs = [(lambda e, hooks, p=p, q=q: e.generate(p, q, max_new=n, min_new=n, hooks=hooks)) for p, q in batches]
@@ -42,6 +44,7 @@ def test_two_lanes_return_what_one_batch_at_a_time_returns(setup):
         assert got == want
     assert pipe.engines[1].k_cache.data_ptr() != eng.k_cache.data_ptr(), "a lane has its own KV cache"
     assert pipe.engines[1].vit is eng.vit and pipe.engines[1].dec is eng.dec, "and shares the bound weights"
+    pipe.order = "lockstep"
 
 
 def test_ordered_calls_run_in_batch_order(setup):
