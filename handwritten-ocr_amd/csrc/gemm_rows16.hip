@@ -26,7 +26,9 @@ using namespace gemm;
 namespace {
 
 constexpr int R16_WAVES = 16;
-constexpr int R16_CH = 8;           // k-steps (1-KiB fragments) a wave keeps in registers at a time
+// k-steps (1-KiB weight fragments) a wave keeps in flight / in registers at a time: 12, or 8 in the instance whose norm prologue holds
+// rows of up to 4096 elements (a 16-wave workgroup leaves a lane 128 registers)
+constexpr int rows16_chunk(int nc) { return nc > 4 ? 8 : 12; }
 constexpr int R16_RED = R16_WAVES * 1024;
 
 struct Rows16Args {
@@ -42,8 +44,11 @@ struct Rows16Args {
   const bf16* norm_w; float eps; int gemma;
 };
 
-template <int EPI, bool NORM>
+// NC: 64-lane chunks of 8 elements a row of the norm prologue may have (4: K <= 2048, 8: K <= 4096); 0: no prologue
+template <int EPI, int NC>
 __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args a) {
+  constexpr bool NORM = NC > 0;
+  constexpr int R16_CH = rows16_chunk(NC);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = (float*)smem;                 // [16 waves][64 lanes][4]: K-slice partial sums
   char* xs = smem + R16_RED;                 // NORM: x image, row r at r * xstride (16 bytes of padding per row: the B-fragment
@@ -51,63 +56,6 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, q = lane >> 4;
-
-  if constexpr (NORM) {
-    const int D = a.K, nch = D >> 3;
-    if (w < a.Bsz) {
-      float x[8][8];  // D <= 4096: 8 chunks of 8 per lane
-      float ss = 0.f;
-      const bool keeper = blockIdx.x == 0 && blockIdx.y == 0 && a.h_out != nullptr;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
-          bf16x8 hv = *(const bf16x8*)(a.h_in + (long)w * a.ldh + ch * 8);
-          if (a.nslab > 0) {
-            // all (<= 4) slabs' loads unconditional and in flight together: a slab past nslab re-reads slab 0 and adds zero
-            f32x4 v[4][2];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const float* p = a.slabs + (long)(s < a.nslab ? s : 0) * a.slab_stride + (long)w * a.ld_slab + ch * 8;
-              v[s][0] = *(const f32x4*)p;
-              v[s][1] = *(const f32x4*)(p + 4);
-            }
-            float y[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) y[e] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              const float on = s < a.nslab ? 1.0f : 0.0f;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { y[e] += on * v[s][0][e]; y[4 + e] += on * v[s][1][e]; }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = f2bf(rbf(y[e]) + bf2f(hv[e]));
-          }
-          if (keeper) *(bf16x8*)(a.h_out + (long)w * a.ldh + ch * 8) = hv;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { x[i][e] = bf2f(hv[e]); ss += x[i][e] * x[i][e]; }
-        }
-      }
-      const float rstd = rsqrtf(wave_sum(ss) / D + a.eps);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
-          const bf16x8 g = *(const bf16x8*)(a.norm_w + ch * 8);
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            o[e] = a.gemma ? f2bf(x[i][e] * rstd * (1.0f + bf2f(g[e]))) : f2bf(bf2f(g[e]) * rbf(x[i][e] * rstd));
-          *(bf16x8*)(xs + w * xstride + ch * 16) = o;
-        }
-      }
-    } else {  // rows past Bsz: zeros (their output columns are never stored)
-      const bf16x8 z = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-      for (int ch = lane; ch < nch; ch += 64) *(bf16x8*)(xs + w * xstride + ch * 16) = z;
-    }
-    __syncthreads();
-  }
 
   constexpr int UNIT = is_glu<EPI> ? 2 : 1;
   const int units = (a.N >> 4) / UNIT;
@@ -121,25 +69,115 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
   const int kb = ks0 + (int)((long)wk * nks / KS), ke = ks0 + (int)((long)(wk + 1) * nks / KS);
   const bool through_lds = KS > 1 || is_glu<EPI>;
 
+  // The first chunk of this wave's weight fragments goes out BEFORE the norm prologue: the loads do not depend on x, and their HBM
+  // latency (the longest thing in the kernel at these sizes) then passes under the prologue instead of after it.
+  bf16x8 wf[R16_CH];
+  const bool on0 = t0 + wt < t1 && ke > kb;   // wave-uniform
+  if (on0) {
+    const bf16* wp = a.W + (size_t)(t0 + wt) * ks_total * 512 + lane * 8;
+#pragma unroll
+    for (int i = 0; i < R16_CH; ++i) wf[i] = __builtin_nontemporal_load((const bf16x8*)(wp + (size_t)min(kb + i, ke - 1) * 512));
+  }
+
+  if constexpr (NORM) {
+    const int D = a.K, nch = D >> 3;
+    if (w < a.Bsz) {
+      // NC chunks of 8 per lane, kept as the bf16 values they are (4 registers a chunk: the weight fragments already in flight take
+      // 32-48 of the 128 a 16-wave workgroup leaves a lane)
+      bf16x8 hs[NORM ? NC : 1];
+      float ss = 0.f;
+      const bool keeper = blockIdx.x == 0 && blockIdx.y == 0 && a.h_out != nullptr;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+          bf16x8 hv = *(const bf16x8*)(a.h_in + (long)w * a.ldh + ch * 8);
+          if (a.nslab > 0) {
+            // the (<= 4) slabs two at a time, loads unconditional (a slab past nslab re-reads slab 0 and adds zero), summed in
+            // ascending slab order
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = 0.f;
+#pragma unroll
+            for (int s0 = 0; s0 < 4; s0 += 2) {
+              f32x4 v[2][2];
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const float* p = a.slabs + (long)(s0 + u < a.nslab ? s0 + u : 0) * a.slab_stride + (long)w * a.ld_slab + ch * 8;
+                v[u][0] = *(const f32x4*)p;
+                v[u][1] = *(const f32x4*)(p + 4);
+              }
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const float on = s0 + u < a.nslab ? 1.0f : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { y[e] += on * v[u][0][e]; y[4 + e] += on * v[u][1][e]; }
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = f2bf(rbf(y[e]) + bf2f(hv[e]));
+          }
+          if (keeper) *(bf16x8*)(a.h_out + (long)w * a.ldh + ch * 8) = hv;
+          hs[i] = hv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float xv = bf2f(hv[e]); ss += xv * xv; }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(ss) / D + a.eps);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+          const bf16x8 g = *(const bf16x8*)(a.norm_w + ch * 8);
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xv = bf2f(hs[i][e]);
+            o[e] = a.gemma ? f2bf(xv * rstd * (1.0f + bf2f(g[e]))) : f2bf(bf2f(g[e]) * rbf(xv * rstd));
+          }
+          *(bf16x8*)(xs + w * xstride + ch * 16) = o;
+        }
+      }
+    } else {  // rows past Bsz: zeros (their output columns are never stored)
+      const bf16x8 z = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+      for (int ch = lane; ch < nch; ch += 64) *(bf16x8*)(xs + w * xstride + ch * 16) = z;
+    }
+    __syncthreads();
+  }
+
+
   for (int tbase = t0; tbase < t1; tbase += TC) {  // workgroup-uniform
     const int tile = tbase + wt;
-    const bool on = tile < t1;                      // wave-uniform
+    const bool mine = tile < t1;                    // wave-uniform: this wave has a tile in this round ...
+    const bool on = mine && ke > kb;                // ... and its K slice is not empty (fewer k-steps than slices: tiny models)
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (on) {
       const bf16* wp = a.W + (size_t)tile * ks_total * 512 + lane * 8;
       const bf16* xp = NORM ? nullptr : a.X + (size_t)min(c, a.Bsz - 1) * a.ldx + q * 8;
       for (int k = kb; k < ke; k += R16_CH) {
-        bf16x8 wf[R16_CH], xf[R16_CH];
+        if (tbase != t0 || k != kb) {               // (the first chunk of the first round is already in flight)
 #pragma unroll
-        for (int i = 0; i < R16_CH; ++i) {
-          const int kk = min(k + i, ke - 1);  // clamped, never a branch around a load
-          wf[i] = __builtin_nontemporal_load((const bf16x8*)(wp + (size_t)kk * 512));
-          if constexpr (NORM) xf[i] = *(const bf16x8*)(xs + c * xstride + kk * 64 + q * 16);
-          else xf[i] = *(const bf16x8*)(xp + kk * 32);
+          for (int i = 0; i < R16_CH; ++i)          // indices clamped, never a branch around a load
+            wf[i] = __builtin_nontemporal_load((const bf16x8*)(wp + (size_t)min(k + i, ke - 1) * 512));
         }
+        if constexpr (NORM) {
 #pragma unroll
-        for (int i = 0; i < R16_CH; ++i)
-          if (k + i < ke) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[i], acc, 0, 0, 0);
+          for (int i0 = 0; i0 < R16_CH; i0 += 4) {  // x fragments from the LDS image, four at a time
+            bf16x8 xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xs + c * xstride + min(k + i0 + i, ke - 1) * 64 + q * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (k + i0 + i < ke) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i0 + i], xf[i], acc, 0, 0, 0);
+          }
+        } else {
+          bf16x8 xf[R16_CH];
+#pragma unroll
+          for (int i = 0; i < R16_CH; ++i) xf[i] = *(const bf16x8*)(xp + min(k + i, ke - 1) * 32);
+#pragma unroll
+          for (int i = 0; i < R16_CH; ++i)
+            if (k + i < ke) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[i], acc, 0, 0, 0);
+        }
       }
     }
     // ---- the K slices of a tile summed in ascending order by the wave that holds slice 0; a gated pair by the gate tile's wave
@@ -147,7 +185,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
     if (through_lds) {
       *(f32x4*)(red + (w * 64 + lane) * 4) = acc;
       __syncthreads();
-      if (wk == 0 && on) {
+      if (wk == 0 && mine) {
         for (int j = 1; j < KS; ++j) acc += *(const f32x4*)(red + ((w + j) * 64 + lane) * 4);
         if constexpr (is_glu<EPI>) {
           if ((wt & 1) == 0)
@@ -156,7 +194,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
       }
     }
     // lane (c, q): acc[r] = out[row c][16 tile + 4 q + r]
-    if (wk == 0 && on && c < a.Bsz) {
+    if (wk == 0 && mine && c < a.Bsz) {
       const int n = 16 * tile + 4 * q;
       if constexpr (EPI == EPI_PARTIAL) {
         *(f32x4*)((float*)a.out + ((size_t)blockIdx.y * a.Bsz + c) * a.ldo + n) = acc;
@@ -185,16 +223,21 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
   }
 }
 
+template <int EPI, int NC>
+int launch_rows16_nc(const Rows16Args& a, dim3 grid, hipStream_t st) {
+  const int lds = R16_RED + (NC ? 16 * (2 * a.K + 16) : 0);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_rows16_kernel<EPI, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_rows16_kernel<EPI, NC>), grid, dim3(64 * R16_WAVES), lds, st, a);
+  return hwocr_launch_status();
+}
 template <int EPI, bool NORM>
 int launch_rows16(const Rows16Args& a, dim3 grid, hipStream_t st) {
-  const int lds = R16_RED + (NORM ? 16 * (2 * a.K + 16) : 0);
-  static int attr_for = 0;
-  if (lds > attr_for) {
-    (void)hipFuncSetAttribute((const void*)gemm_rows16_kernel<EPI, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_for = 160 * 1024;
-  }
-  hipLaunchKernelGGL((gemm_rows16_kernel<EPI, NORM>), grid, dim3(64 * R16_WAVES), lds, st, a);
-  return hwocr_launch_status();
+  if constexpr (!NORM) return launch_rows16_nc<EPI, 0>(a, grid, st);
+  else return a.K <= 2048 ? launch_rows16_nc<EPI, 4>(a, grid, st) : launch_rows16_nc<EPI, 8>(a, grid, st);
 }
 
 int pow2_at_least(int v) {
@@ -235,7 +278,7 @@ extern "C" int hwocr_gemm_rows16(const void* X, int ldx, const void* Wt, void* o
                norm ? norm->slabs : nullptr, norm ? norm->nslab : 0, norm ? norm->slab_stride : 0, norm ? norm->ld_slab : 0,
                norm ? (const bf16*)norm->norm_w : nullptr, norm ? norm->eps : 0.f, norm ? norm->gemma : 0};
   const dim3 grid(groups, splitk);
-  HWOCR_PLAN("gemm_rows16_kernel<epi=%d,%s> tc=%d %s rows=%d N=%d K=%d splitk=%d groups=%d nslab=%d", epi, norm ? "norm" : "plain", tc,
+  HWOCR_PLAN("gemm_rows16_kernel<epi=%d,%s> tc=%d %s rows=%d N=%d K=%d splitk=%d groups=%d nslab=%d", epi, norm ? (K <= 2048 ? "norm4" : "norm8") : "plain", tc,
              tiles_per_wg > tc ? "rounds>1" : "rounds=1", Bsz, N, K, splitk, groups, norm ? norm->nslab : 0);
   if (norm) {
     switch (epi) {
