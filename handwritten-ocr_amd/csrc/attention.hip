@@ -283,19 +283,23 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attn_hd256_kernel(PrefillArgs a
   const int vd = 8 * w + (lane >> 3);
   const long vofs = (long)vd * a.v_row + (((lane & 7) ^ ((vd >> 1) & 7)) << 3);
   static_assert(WAVES == 4 || WAVES == 8, "task -> row arithmetic below assumes 2 WAVES | 16 and 8 WAVES | 64");
-  auto stage_tile = [&](int t) {
+  // piece i of this wave's N_DMA DMA instructions for tile t: the first half K rows, the second half V^T rows
+  auto stage_piece = [&](int t, int i) {
     const int j0 = t * 64;
     char* st = smem + (t & 1) * G256_STAGE;
-#pragma unroll
-    for (int e = 0; e < N_DMA / 2; ++e) {  // K: task w + WAVES e -> rows krow + 2 WAVES e
+    if (i < N_DMA / 2) {  // K: task w + WAVES e -> rows krow + 2 WAVES e
+      const int e = i;
       const bf16* src = Kp + (long)(j0 + 2 * WAVES * e) * a.k_row + ((e & 1) && WAVES == 4 ? kofs1 : kofs0);
       __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR(st + (w + WAVES * e) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int e = 0; e < N_DMA / 2; ++e) {  // V^T: task 32 + w + WAVES e -> d rows vd + 8 WAVES e (same swizzle: 8 WAVES e / 2 = 0 mod 8)
+    } else {              // V^T: task 32 + w + WAVES e -> d rows vd + 8 WAVES e (same swizzle: 8 WAVES e / 2 = 0 mod 8)
+      const int e = i - N_DMA / 2;
       const bf16* src = Vp + (long)(8 * WAVES * e) * a.v_row + j0 + vofs;
       __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR(st + G256_K + (w + WAVES * e) * 1024), 16, 0, 0);
     }
+  };
+  auto stage_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < N_DMA; ++i) stage_piece(t, i);
   };
 
   f32x16 o[ND];
@@ -311,7 +315,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attn_hd256_kernel(PrefillArgs a
   for (int t = 0; t < nt; ++t) {
     const int j0 = t * 64;
     char* st = smem + (t & 1) * G256_STAGE;
-    if (t + 1 < nt) stage_tile(t + 1);  // into the stage tile t-1 occupied: every wave passed the barrier that ended it
+    // Tile t + 1 goes into the stage tile t - 1 occupied (every wave passed the barrier that ended it) piece by piece, one DMA
+    // instruction behind each pair of score MFMAs below: a lone wave per SIMD pays ~100 cycles to ISSUE an LDS-DMA instruction
+    // (tools/bench_vit80x_stamps.py), and the 16 of a tile issued in one burst at the top of the step held the matrix pipe idle
+    // for 1600 of the step's ~6000 cycles.
+    const bool more = t + 1 < nt;
     if (j0 + 64 > len) {
       // tail tile: keys past the read must contribute 0 * finite; their V^T columns are whatever the cache holds
       for (int i = tid; i < HD * 64; i += NT) {
@@ -348,6 +356,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attn_hd256_kernel(PrefillArgs a
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * (s & 3)], qf[s], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * (s & 3) + 1], qf[s], s1, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (more && s < N_DMA) stage_piece(t + 1, s);
       if (s + 4 < NS) {
         fr[2 * (s & 3)] = k_frag(s + 4, 0);
         fr[2 * (s & 3) + 1] = k_frag(s + 4, 1);

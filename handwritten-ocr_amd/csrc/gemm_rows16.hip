@@ -73,10 +73,21 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
   // latency (the longest thing in the kernel at these sizes) then passes under the prologue instead of after it.
   bf16x8 wf[R16_CH];
   const bool on0 = t0 + wt < t1 && ke > kb;   // wave-uniform
-  if (on0) {
-    const bf16* wp = a.W + (size_t)(t0 + wt) * ks_total * 512 + lane * 8;
+  // (loads go out in groups of four k-steps: a group is skipped - a wave-uniform branch - when the slice ends before it, so a short
+  // slice does not re-request its last fragment up to eleven times; inside a group indices are clamped, never a branch per load)
+  auto load_w = [&](const bf16* wp, int k) {
 #pragma unroll
-    for (int i = 0; i < R16_CH; ++i) wf[i] = __builtin_nontemporal_load((const bf16x8*)(wp + (size_t)min(kb + i, ke - 1) * 512));
+    for (int g = 0; g < R16_CH; g += 4)
+      if (k + g < ke) {
+#pragma unroll
+        for (int i = g; i < g + 4; ++i) wf[i] = __builtin_nontemporal_load((const bf16x8*)(wp + (size_t)min(k + i, ke - 1) * 512));
+      }
+  };
+  if (on0) load_w(a.W + (size_t)(t0 + wt) * ks_total * 512 + lane * 8, kb);
+  // the residual rows of the first round's epilogue likewise: nothing they depend on is computed here
+  bf16x4 res0 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  if constexpr (EPI == EPI_RESIDUAL) {
+    if (wk == 0 && t0 + wt < t1 && c < a.Bsz) res0 = *(const bf16x4*)((const bf16*)a.out + (size_t)c * a.ldo + 16 * (t0 + wt) + 4 * q);
   }
 
   if constexpr (NORM) {
@@ -123,12 +134,16 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
           for (int e = 0; e < 8; ++e) { const float xv = bf2f(hv[e]); ss += xv * xv; }
         }
       }
+      bf16x8 gw[NORM ? NC : 1];   // the norm weights, requested before the row statistic is reduced
+#pragma unroll
+      for (int i = 0; i < NC; ++i)
+        if (lane + 64 * i < nch) gw[i] = *(const bf16x8*)(a.norm_w + (lane + 64 * i) * 8);
       const float rstd = rsqrtf(wave_sum(ss) / D + a.eps);
 #pragma unroll
       for (int i = 0; i < NC; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
-          const bf16x8 g = *(const bf16x8*)(a.norm_w + ch * 8);
+          const bf16x8 g = gw[i];
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -155,14 +170,11 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
       const bf16* wp = a.W + (size_t)tile * ks_total * 512 + lane * 8;
       const bf16* xp = NORM ? nullptr : a.X + (size_t)min(c, a.Bsz - 1) * a.ldx + q * 8;
       for (int k = kb; k < ke; k += R16_CH) {
-        if (tbase != t0 || k != kb) {               // (the first chunk of the first round is already in flight)
-#pragma unroll
-          for (int i = 0; i < R16_CH; ++i)          // indices clamped, never a branch around a load
-            wf[i] = __builtin_nontemporal_load((const bf16x8*)(wp + (size_t)min(k + i, ke - 1) * 512));
-        }
+        if (tbase != t0 || k != kb) load_w(wp, k);  // (the first chunk of the first round is already in flight)
         if constexpr (NORM) {
 #pragma unroll
           for (int i0 = 0; i0 < R16_CH; i0 += 4) {  // x fragments from the LDS image, four at a time
+            if (k + i0 >= ke) break;
             bf16x8 xf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8*)(xs + c * xstride + min(k + i0 + i, ke - 1) * 64 + q * 16);
@@ -173,7 +185,11 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
         } else {
           bf16x8 xf[R16_CH];
 #pragma unroll
-          for (int i = 0; i < R16_CH; ++i) xf[i] = *(const bf16x8*)(xp + min(k + i, ke - 1) * 32);
+          for (int g = 0; g < R16_CH; g += 4)
+            if (k + g < ke) {
+#pragma unroll
+              for (int i = g; i < g + 4; ++i) xf[i] = *(const bf16x8*)(xp + min(k + i, ke - 1) * 32);
+            }
 #pragma unroll
           for (int i = 0; i < R16_CH; ++i)
             if (k + i < ke) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[i], acc, 0, 0, 0);
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
         *(f32x4*)((float*)a.out + ((size_t)blockIdx.y * a.Bsz + c) * a.ldo + n) = acc;
       } else if constexpr (EPI == EPI_RESIDUAL) {
         bf16* hp = (bf16*)a.out + (size_t)c * a.ldo + n;
-        const bf16x4 h = *(const bf16x4*)hp;
+        const bf16x4 h = tbase == t0 ? res0 : *(const bf16x4*)hp;
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(acc[r]) + bf2f(h[r]));

@@ -84,9 +84,31 @@ def _load_ocr_model():
     return _ocr_model, _ocr_processor
 
 
+_ocr_lanes = None  # pipeline.LanePipeline over _ocr_model, made on the first batch that has more reads than decode slots
+
+
+def _lanes():
+    """Two (HWOCR_LANES) sets of read slots over the loaded weights, each on its own stream and host thread: a batch with more reads
+    than one lane has slots is dealt over them (pipeline.py: +6 % pages/s on the MI355X, same tokens).  None: one lane."""
+    global _ocr_lanes
+    n = int(os.environ.get("HWOCR_LANES", "2"))
+    if n <= 1 or _ocr_model is None:
+        return None
+    if _ocr_lanes is None or _ocr_lanes.engines[0] is not _ocr_model or len(_ocr_lanes.engines) != n:
+        from . import pipeline
+
+        if _ocr_lanes is not None:
+            _ocr_lanes.close()
+        _ocr_lanes = pipeline.LanePipeline(_ocr_model, lanes=n)
+    return _ocr_lanes
+
+
 def unload_ocr_model():
-    global _ocr_model, _ocr_processor
+    global _ocr_model, _ocr_processor, _ocr_lanes
     if os.environ.get("HWOCR_KEEP_RESIDENT", "1") == "0" and _ocr_model is not None:
+        if _ocr_lanes is not None:
+            _ocr_lanes.close()
+            _ocr_lanes = None
         _ocr_model.close()
         _ocr_model = None
         _ocr_processor = None
@@ -118,9 +140,20 @@ def run_ocr_batch_tokens(images: list, params: dict | None = None) -> list[list[
         prompts.append(ids)
     # continuous batching: reads stop at different lengths (EOS), freed decode slots take the next read
     # (read_ids: the caller's numbering of the reads - it keys the sampling RNG, so that a sampled read does not depend on the shard)
-    return model.generate_stream(pages, prompts, max_new=max_new, min_new=min_new,
-                                 repetition_penalty=params.get("repetition_penalty"),  # None: the checkpoint's default
-                                 read_ids=params.get("read_ids"))
+    rp = params.get("repetition_penalty")  # None: the checkpoint's default
+    ids = params.get("read_ids")
+    pipe = _lanes() if len(pages) > model.max_reads else None
+    if pipe is None:
+        return model.generate_stream(pages, prompts, max_new=max_new, min_new=min_new, repetition_penalty=rp, read_ids=ids)
+    # more reads than one lane has slots: contiguous shares of the reads, one per lane, side by side (a read's tokens do not depend
+    # on its lane: the RNG of a sampled read is keyed by the caller's read number)
+    ids = list(range(len(pages))) if ids is None else list(ids)
+    n = len(pipe.engines)
+    cuts = [len(pages) * i // n for i in range(n + 1)]
+    jobs = [(lambda e, hooks, lo=lo, hi=hi: e.generate_stream(pages[lo:hi], prompts[lo:hi], max_new=max_new, min_new=min_new,
+                                                               repetition_penalty=rp, read_ids=ids[lo:hi]))
+            for lo, hi in zip(cuts[:-1], cuts[1:])]
+    return [t for part in pipe.run(jobs) for t in part]
 
 
 def decode_tokens(streams: list) -> list[str]:

@@ -309,6 +309,42 @@ def test_drop_in_tools_surface(tmp_path, monkeypatch, capsys):
     assert tools._ocr_model is None
 
 
+def test_run_ocr_batch_deals_reads_over_two_lanes(tmp_path, monkeypatch):
+    """More reads than one lane has decode slots: run_ocr_batch_tokens deals them over two lanes (two streams, two host threads,
+    pipeline.LanePipeline) — same token streams as the single lane, in the caller's order, greedy and sampled (the RNG of a sampled
+    read is keyed by the caller's read number, not by its lane)."""
+    from handwritten_ocr_amd import tools
+    from handwritten_ocr_amd.compat import config
+    from handwritten_ocr_amd.synth import make_page
+
+    monkeypatch.setenv("HWOCR_MODEL", "tiny")
+    monkeypatch.setenv("HWOCR_ALLOW_RANDOM_INIT", "1")
+    monkeypatch.setenv("HWOCR_MAX_READS", "6")
+    monkeypatch.setenv("HWOCR_CTX", "512")
+    monkeypatch.setenv("HWOCR_KEEP_RESIDENT", "0")
+    monkeypatch.setattr(tools, "_ocr_model", None)
+    monkeypatch.setattr(tools, "_ocr_processor", None)
+    monkeypatch.setattr(tools, "_ocr_lanes", None)
+    monkeypatch.setattr(config, "OCR_MIN_PIXELS", 28 * 28)
+    imgs = [Image.fromarray(make_page(60 + i, 70 + 14 * (i % 3), 100), "RGB") for i in range(17)]
+    params = {"max_new_tokens": 10, "min_new_tokens": 3}
+    monkeypatch.setenv("HWOCR_LANES", "1")
+    want = tools.run_ocr_batch_tokens(imgs, params)
+    assert tools._ocr_lanes is None
+    monkeypatch.setenv("HWOCR_LANES", "2")
+    got = tools.run_ocr_batch_tokens(imgs, params)
+    assert tools._ocr_lanes is not None and len(tools._ocr_lanes.engines) == 2
+    assert got == want and len(got) == 17
+    assert tools.run_ocr_batch_tokens(imgs[:5], params) == want[:5]   # fits one lane: no dealing
+    tools._ocr_model.cfg.do_sample, tools._ocr_model.cfg.temperature, tools._ocr_model.cfg.top_k = True, 1.0, 20
+    a = tools.run_ocr_batch_tokens(imgs, params)
+    monkeypatch.setenv("HWOCR_LANES", "1")
+    b = tools.run_ocr_batch_tokens(imgs, params)
+    assert a == b and a != want
+    tools.unload_ocr_model()
+    assert tools._ocr_model is None and tools._ocr_lanes is None
+
+
 def test_batch_folder_cli_end_to_end(tmp_path, monkeypatch, capsys):
     """`python -m handwritten_ocr_amd.batch <folder>` on the real engine (tiny preset): one batched pass for all pages and
     strategies, the reference's four files per page, texts equal to per-page `run_ocr` reads merged by the same node code."""
