@@ -13,6 +13,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python3 
     > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_rocprof.err
 cp /tmp/prof_ks/*/*_kernel_stats.csv $OUT/${TAG}_kernel_stats_bench_default.csv
 echo "kernel stats done"
+# the same with one batch at a time (--lanes 1): per-launch durations of kernels that have the chip to themselves (with two lanes two
+# launches run side by side and each takes about twice as long)
+rm -rf /tmp/prof_ks1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks1 -- python3 $R/bench.py --lanes 1 --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" \
+    > $OUT/${TAG}_bench_one_lane_under_rocprof.json 2>> $OUT/${TAG}_rocprof.err
+cp /tmp/prof_ks1/*/*_kernel_stats.csv $OUT/${TAG}_kernel_stats_bench_one_lane.csv
+rm -rf /tmp/prof_ks1
+echo "one-lane kernel stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python3 $R/bench.py --pages 12 --steps 1 --warmup 0 --new-tokens 4 \
     --no-cpu-baseline --no-extras "$@" > /dev/null 2>> $OUT/${TAG}_rocprof.err
 echo "fetch pass done"
