@@ -412,15 +412,12 @@ def main() -> None:
     lib = _lib.hip()
     pre_ms = []
 
-    def read_and_merge(pages, n_pages, e=None, hooks=None):
-        e = e or eng
-        toks = e.generate(pages, prompts[: len(pages)], max_new=args.new_tokens, min_new=args.new_tokens, hooks=hooks)
+    deferred = []  # world > 1 with lanes: (step, token streams) whose gather + merge the MAIN thread does after the lanes are done
+
+    def gather_and_merge(toks, n_pages):
         t = torch.tensor(toks, dtype=torch.int32, device=dev)
         counts = torch.full((len(toks),), args.new_tokens, dtype=torch.int32, device=dev)
-        if hooks is not None:   # every rank must issue its gathers in batch order although two host threads drive each GPU
-            hooks.ordered(lambda: shard.gather_token_streams(t, counts, dst=0))
-        else:
-            shard.gather_token_streams(t, counts, dst=0)
+        shard.gather_token_streams(t, counts, dst=0)
         merged = []
         for p in range(n_pages):
             reads = [tok.decode(toks[p * args.reads + r]) for r in range(args.reads)]
@@ -428,6 +425,16 @@ def main() -> None:
                 text.compare_versions(reads[0], reads[1])
             merged.append(text.merge_versions(reads))
         return merged
+
+    def read_and_merge(pages, n_pages, e=None, hooks=None):
+        e = e or eng
+        toks = e.generate(pages, prompts[: len(pages)], max_new=args.new_tokens, min_new=args.new_tokens, hooks=hooks)
+        if hooks is not None and world > 1:
+            # a lane's host thread issues no collective: RCCL wants every rank to issue its collectives in one order, from one
+            # thread; the gathers (and the merges behind them) are done by the main thread, in step order, inside the timed region
+            deferred.append((hooks.k, toks))
+            return None
+        return gather_and_merge(toks, n_pages)
 
     def step(src=None, e=None, hooks=None):
         """One step on engine (lane) e.  src: device-resident raw pages (the timed configuration) or host arrays (upload inside the
@@ -443,7 +450,11 @@ def main() -> None:
 
     def run_steps(k, src=None):
         """k steps through the lanes (lanes == 1: one after the other on this thread's stream): their phase times in step order."""
-        return pipe.run([(lambda e, hooks, src=src: step(src, e, hooks)) for _ in range(k)])
+        out = pipe.run([(lambda e, hooks, src=src: step(src, e, hooks)) for _ in range(k)])
+        for _, toks in sorted(deferred, key=lambda d: d[0]):
+            gather_and_merge(toks, args.pages)
+        deferred.clear()
+        return out
 
     def barrier():
         if world > 1:

@@ -17,8 +17,9 @@ tokens per batch, tokens identical to the serial schedule in every arm; profiles
 `LanePipeline(order="lockstep")` (the default) is the second row made the rule: the lanes start together and, doing equal work, stay
 in step; nothing orders them on the device.  `order="alternate"` is the fourth row (kept selectable: it is the schedule VERDICT r2
 asked to be measured): tower(k) waits for prefill(k-1), decode(k) for decode(k-1), by HIP events (`ReadEngine.generate(hooks=...)`).
-Either way everything after a batch's decode (token gather, detokenise, compare / merge on the host) runs in that batch's thread,
-and `hooks.ordered()` serialises what all ranks of a multi-GPU run must issue in the same order (the RCCL gather).
+Either way everything after a batch's decode (detokenise, compare / merge on the host) runs in that batch's thread; `hooks.ordered()`
+serialises per-batch side effects in batch order.  Collectives are NOT issued from lane threads (RCCL wants one issuing order on every
+rank): with several ranks the caller gathers the batches' token streams from its main thread after `run()` (bench.py).
 
 Results are those of the serial schedule bit for bit: a lane is an ordinary engine over the same weights (`ReadEngine.lane()`: own
 KV cache / state / workspaces) and batches never share state.
