@@ -309,6 +309,36 @@ def test_drop_in_tools_surface(tmp_path, monkeypatch, capsys):
     assert tools._ocr_model is None
 
 
+def test_the_two_decode_paths_agree_within_rounding():
+    """At most 16 reads in flight a decode step runs the 6-launch layer of csrc/gemm_rows16.hip, above that the general 7-launch layer:
+    the same read decoded alone and inside a batch of 20 goes through different kernels (other split-K structure, other summation
+    order of the norm statistic), so its logits agree to rounding, not bit for bit — held here to half of the tolerance the
+    engine is held to against HF (teacher-forced, both families' tiny goldens are in the fixtures above; here the `small` preset's
+    widths: 768 hidden = the two-chunk norm instances, 6 q / 2 kv heads)."""
+    from handwritten_ocr_amd import engine, imageproc, synth, tokenizer
+    from handwritten_ocr_amd.compat import config
+
+    cfg = engine.preset("small")
+    e = engine.ReadEngine(cfg, engine.random_state_dict(cfg, seed=3, device="cuda"), max_reads=20, ctx=640, vit_batch=4, prefill_batch=8)
+    try:
+        proc = tokenizer.Processor(cfg, tokenizer.ByteTokenizer(cfg, fold_unknown=True))
+        pages = [imageproc.prepare_page(Image.fromarray(synth.make_page(200 + i, 300, 420), "RGB"), cfg.patch_size, cfg.merge,
+                                        config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS) for i in range(20)]
+        prompts = [proc.chat_ids(config.OCR_PROMPT, proc.image_tokens(p)) for p in pages]
+        n = 10
+        forced = np.random.default_rng(0).integers(0, 255, size=(20, n)).astype(np.int32)
+        plan1, plan20 = engine.decode_plan(cfg, 3), engine.decode_plan(cfg, 20)
+        assert "gemm_rows16_kernel" in plan1["qkv"][4] and "gemm_stream_kernel" in plan20["qkv"][4]
+        _, big = e.generate(pages, prompts, max_new=n, min_new=n, forced=forced, return_logits=True)
+        _, few = e.generate(pages[:3], prompts[:3], max_new=n, min_new=n, forced=forced[:3], return_logits=True)
+        a, b = big[:3].float(), few.float()
+        scale = max(1.0, float(b.abs().max()))
+        d = (a - b).abs()
+        assert float(d.mean()) <= 2.5e-3 * scale and float(d.max()) <= 3e-2 * scale, (float(d.mean()), float(d.max()), scale)
+    finally:
+        e.close()
+
+
 def test_run_ocr_batch_deals_reads_over_two_lanes(tmp_path, monkeypatch):
     """More reads than one lane has decode slots: run_ocr_batch_tokens deals them over two lanes (two streams, two host threads,
     pipeline.LanePipeline) — same token streams as the single lane, in the caller's order, greedy and sampled (the RNG of a sampled
