@@ -77,9 +77,10 @@ class _JobHooks:
         """The job raised before reaching a phase boundary: release whoever waits on it (their wait_event is then a no-op)."""
         for rec, evs in ((self.pipe._prefill_recorded, self.pipe._prefill_done), (self.pipe._decode_recorded, self.pipe._decode_done)):
             if not rec[self.k].is_set():
-                ev = torch.cuda.Event()
-                ev.record()
-                evs[self.k] = ev
+                if self.pipe.streams is not None:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    evs[self.k] = ev
                 rec[self.k].set()
         self.pipe._ordered_done[self.k].set()
 
@@ -93,7 +94,8 @@ class LanePipeline:
         self.order = order
         self.engines = [engine] + [engine.lane() for _ in range(lanes - 1)]
         self.device = engine.dev
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.engines]
+        # (no device: the thread / ordering logic alone, for the CPU test of it — a ReadEngine always has one)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.engines] if self.device is not None else None
 
     def close(self) -> None:
         for e in self.engines[1:]:
@@ -111,24 +113,31 @@ class LanePipeline:
         self._ordered_done = {k: threading.Event() for k in range(n)}
         self._prefill_done, self._decode_done = {}, {}
         results, errors = [None] * n, []
-        caller = torch.cuda.current_stream(self.device)
-        start = torch.cuda.Event()
-        start.record(caller)
+        gpu = self.streams is not None
+        if gpu:
+            caller = torch.cuda.current_stream(self.device)
+            start = torch.cuda.Event()
+            start.record(caller)
+
+        def lane_jobs(lane: int) -> None:
+            for k in range(lane, n, len(self.engines)):
+                hooks = _JobHooks(self, k)
+                try:
+                    if errors:
+                        raise RuntimeError("an earlier batch of the pipeline failed")
+                    results[k] = jobs[k](self.engines[lane], hooks)
+                except BaseException as e:  # noqa: BLE001  (re-raised by run())
+                    errors.append(e)
+                finally:
+                    hooks.abandon()
 
         def worker(lane: int) -> None:
+            if not gpu:
+                return lane_jobs(lane)
             torch.cuda.set_device(self.device)
             with torch.cuda.stream(self.streams[lane]):
                 self.streams[lane].wait_event(start)      # what the caller queued before run() (uploads, preprocessing) comes first
-                for k in range(lane, n, len(self.engines)):
-                    hooks = _JobHooks(self, k)
-                    try:
-                        if errors:
-                            raise RuntimeError("an earlier batch of the pipeline failed")
-                        results[k] = jobs[k](self.engines[lane], hooks)
-                    except BaseException as e:  # noqa: BLE001  (re-raised by run())
-                        errors.append(e)
-                    finally:
-                        hooks.abandon()
+                lane_jobs(lane)
                 self.streams[lane].synchronize()
 
         threads = [threading.Thread(target=worker, args=(i,), name=f"hwocr-lane{i}") for i in range(len(self.engines))]
@@ -136,8 +145,9 @@ class LanePipeline:
             t.start()
         for t in threads:
             t.join()
-        for s in self.streams:  # later work on the caller's stream sees the lanes' results
-            caller.wait_stream(s)
+        if gpu:
+            for s in self.streams:  # later work on the caller's stream sees the lanes' results
+                caller.wait_stream(s)
         if errors:
             raise errors[0]
         return results
