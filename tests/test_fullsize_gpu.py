@@ -62,3 +62,51 @@ def test_graph_replay_equals_eager_and_duplicates_agree(setup):
     lg = eng._bufs["logits"][:3].float()
     assert torch.isfinite(lg).all()
     assert torch.equal(lg[0], lg[2]) and not torch.equal(lg[0], lg[1])
+
+
+def test_one_batch_at_the_benchs_geometry():
+    """`python bench.py`'s own batch: 84 pages x 3 strategy reads = 252 reads in flight, 12 pages per tower launch (62 208 rows), 16
+    prompts per prefill launch (21 504 rows), the 252-row decode kernels (the full-size tests above stop at
+    vit_batch 3 / 8 reads).  No oracle finishes 252 full-size reads in seconds, so the batch is held (1) to itself — strategies 0 and 1
+    hand the model identical pixels when OpenCV is absent (deskew is the identity), so reads 3p and 3p + 1 must be bit-identical,
+    and a different page must not be — and (2) to the SAME reads run as a small batch (2 pages per tower launch, 6 prompts per
+    prefill launch, the <= 16-read decode path), whose logits they must match to rounding: the tower / prefill rows are
+    independent of their company bit for bit, the two decode paths agree to half the engine-vs-HF tolerance."""
+    from handwritten_ocr_amd import engine, gpupre, synth
+    from handwritten_ocr_amd.compat import config
+
+    import bench
+
+    cfg = engine.preset("qwen2-vl-2b")
+    sd = engine.random_state_dict(cfg, seed=0, device="cuda")
+    big = engine.ReadEngine(cfg, sd, max_reads=252, ctx=2048, vit_batch=12, prefill_batch=16)
+    del sd
+    small = big.lane()
+    small.vit_batch, small.prefill_batch = 2, 6
+    try:
+        strategies = list(config.PREPROCESSING_STRATEGIES[:3])
+        if not all(gpupre.supported(s) for s in strategies):
+            pytest.skip("OpenCV is importable: the device preprocessing does not restate the cv2 branches")
+        sp = gpupre.StrategyPages("cuda")
+        hw = bench.target_hw(cfg, 1024)
+        pages = [im for p in range(84) for im in sp.pages(torch.from_numpy(np.ascontiguousarray(synth.make_page(500 + p, 1024, 1024))).cuda(), strategies, hw)]
+        n_img = (hw[0] // cfg.patch_size) * (hw[1] // cfg.patch_size) // cfg.merge ** 2
+        prompts = [bench.synthetic_prompt(cfg, n_img)] * len(pages)
+        n = 4
+        forced = np.random.default_rng(1).integers(0, 1000, size=(len(pages), n)).astype(np.int32)
+        _, lg = big.generate(pages, prompts, max_new=n, min_new=n, forced=forced, return_logits=True)
+        assert torch.isfinite(lg.float()).all()
+        for p in (0, 41, 83):
+            assert torch.equal(lg[3 * p], lg[3 * p + 1]), "strategies 0 and 1 see the same pixels: same logits, bit for bit"
+            assert not torch.equal(lg[3 * p], lg[3 * p + 2])
+        assert not torch.equal(lg[0], lg[3])
+        sub = [0, 1, 2, 249, 250, 251]
+        _, ls = small.generate([pages[i] for i in sub], [prompts[i] for i in sub], max_new=n, min_new=n, forced=forced[sub], return_logits=True)
+        a, b = lg[sub].float(), ls.float()
+        assert torch.equal(a[:, 0], b[:, 0]), "the prefill's logits do not depend on the launch geometry"
+        scale = max(1.0, float(b.abs().max()))
+        d = (a - b).abs()
+        assert float(d.mean()) <= 2.5e-3 * scale and float(d.max()) <= 3e-2 * scale, (float(d.mean()), float(d.max()), scale)
+    finally:
+        small.close()
+        big.close()
