@@ -93,7 +93,7 @@ def test_one_batch_at_the_benchs_geometry():
         n_img = (hw[0] // cfg.patch_size) * (hw[1] // cfg.patch_size) // cfg.merge ** 2
         prompts = [bench.synthetic_prompt(cfg, n_img)] * len(pages)
         n = 4
-        forced = np.random.default_rng(1).integers(0, 1000, size=(len(pages), n)).astype(np.int32)
+        forced = np.tile(np.random.default_rng(1).integers(0, 1000, size=(1, n)).astype(np.int32), (len(pages), 1))  # the same fed tokens for every read
         _, lg = big.generate(pages, prompts, max_new=n, min_new=n, forced=forced, return_logits=True)
         assert torch.isfinite(lg.float()).all()
         for p in (0, 41, 83):
