@@ -10,7 +10,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 10  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
+ABI_VERSION = 11  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
 
 P = C.c_void_p
 I = C.c_int
@@ -152,6 +152,7 @@ _HIP_SIGS = {
     "hwocr_decode_graph_destroy": ([P], I),
     "hwocr_img_luma_sum": ([P, L, P, P], I),
     "hwocr_img_contrast": ([P, P, L, I, F, P], I),
+    "hwocr_img_contrast_dev": ([P, P, L, P, L, F, P], I),
     "hwocr_img_binarize": ([P, P, L, P], I),
     "hwocr_img_sharpen": ([P, P, I, I, P], I),
     "hwocr_img_resize_bicubic": ([P, P, P, I, I, I, I, P, P, I, P, P, I, P], I),

@@ -34,6 +34,17 @@ __global__ __launch_bounds__(256) void contrast_kernel(const unsigned char* src,
   }
 }
 
+// the same blend with the mean taken from the device: mean = int(sum / npix + 0.5) in double, which is Python's
+// int(int(sum) / n + 0.5) (both operands below 2^53, one correctly rounded division) - no host round trip between the two kernels
+__global__ __launch_bounds__(256) void contrast_dev_kernel(const unsigned char* src, unsigned char* dst, long nbytes,
+                                                           const unsigned long long* sum, long npix, float factor) {
+  const int mean = (int)((double)*sum / (double)npix + 0.5);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nbytes; i += (long)gridDim.x * 256) {
+    const float t = (float)((float)mean + factor * (float)((int)src[i] - mean));
+    dst[i] = t <= 0.0f ? 0 : (t >= 255.0f ? 255 : (unsigned char)t);
+  }
+}
+
 __global__ __launch_bounds__(256) void binarize_kernel(const unsigned char* rgb, unsigned char* dst, long npix) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
     const unsigned char v = luma(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]) > 128 ? 255 : 0;
@@ -116,6 +127,15 @@ extern "C" int hwocr_img_contrast(const void* src, void* dst, long nbytes, int m
   if (!src || !dst || nbytes <= 0 || mean < 0 || mean > 255) return HWOCR_EINVAL;
   hipLaunchKernelGGL(contrast_kernel, dim3(blocks_for(nbytes)), dim3(256), 0, stream, (const unsigned char*)src,
                      (unsigned char*)dst, nbytes, mean, factor);
+  return hwocr_launch_status();
+}
+
+extern "C" int hwocr_img_contrast_dev(const void* src, void* dst, long nbytes, const unsigned long long* sum, long npix,
+                                      float factor, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!src || !dst || !sum || nbytes <= 0 || npix <= 0) return HWOCR_EINVAL;
+  hipLaunchKernelGGL(contrast_dev_kernel, dim3(blocks_for(nbytes)), dim3(256), 0, stream, (const unsigned char*)src,
+                     (unsigned char*)dst, nbytes, sum, npix, factor);
   return hwocr_launch_status();
 }
 

@@ -109,10 +109,11 @@ class StrategyPages:
     def high_contrast(self, img: torch.Tensor) -> torch.Tensor:
         n = int(img.shape[0]) * int(img.shape[1])
         _lib.check(self.lib.hwocr_img_luma_sum(_lib.ptr(img), n, _lib.ptr(self._sum), _lib.stream_handle()), "hwocr_img_luma_sum")
-        mean = int(int(self._sum.item()) / n + 0.5)  # ImageEnhance.Contrast: int(ImageStat.Stat(L).mean[0] + 0.5)
+        # ImageEnhance.Contrast: mean = int(ImageStat.Stat(L).mean[0] + 0.5), taken on the device (a .item() here would wait for
+        # everything queued on the stream - with two lanes in flight that was 84 waits behind the other lane's kernels per batch)
         out = torch.empty_like(img)
-        _lib.check(self.lib.hwocr_img_contrast(_lib.ptr(img), _lib.ptr(out), 3 * n, mean, 2.0, _lib.stream_handle()),
-                   "hwocr_img_contrast")
+        _lib.check(self.lib.hwocr_img_contrast_dev(_lib.ptr(img), _lib.ptr(out), 3 * n, _lib.ptr(self._sum), n, 2.0,
+                                                   _lib.stream_handle()), "hwocr_img_contrast_dev")
         return out
 
     def binarize(self, img: torch.Tensor) -> torch.Tensor:

@@ -38,7 +38,7 @@ typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
 #define HWOCR_EPI_GELU_TANH 6 /* nn.GELU(approximate="tanh"): SigLIP MLP (HF siglip/modeling_siglip.py:310-322) */
 #define HWOCR_EPI_GEGLU 7     /* SWIGLU's interleaved tile pairs with the tanh GELU as gate: Gemma MLP (HF gemma/modeling_gemma.py:84-97) */
 
-#define HWOCR_ABI_VERSION 10 /* bumped whenever a signature or struct layout below changes */
+#define HWOCR_ABI_VERSION 11 /* bumped whenever a signature or struct layout below changes */
 int hwocr_abi_version(void);
 /* text of the most recent launch failure in this process ("" if none): launcher name + HIP error */
 const char* hwocr_last_error(void);
@@ -362,6 +362,10 @@ int hwocr_decode_graph_destroy(void* graph);
  * (HF image_processing_pil_qwen2_vl.py:152-183 -> Pillow Resample.c), bit-identical to Pillow.  Images: uint8 [H][W][3]. */
 int hwocr_img_luma_sum(const void* rgb, long npix, unsigned long long* sum, hwocr_stream_t stream); /* sum of convert("L") */
 int hwocr_img_contrast(const void* src, void* dst, long nbytes, int mean, float factor, hwocr_stream_t stream);
+/* the same with mean = int(*sum / npix + 0.5) computed on the device from hwocr_img_luma_sum's result (same stream): ImageEnhance.Contrast
+ * without a host round trip between the two kernels */
+int hwocr_img_contrast_dev(const void* src, void* dst, long nbytes, const unsigned long long* sum, long npix, float factor,
+                           hwocr_stream_t stream);
 int hwocr_img_binarize(const void* rgb, void* dst_rgb, long npix, hwocr_stream_t stream);
 int hwocr_img_sharpen(const void* src, void* dst, int H, int W, hwocr_stream_t stream); /* src != dst */
 /* tmp: H * out_w * 3 bytes; bounds [n_out][2] = (first tap, taps), coef [n_out][ksize] = Pillow's 22-bit fixed-point taps */

@@ -39,6 +39,30 @@ def test_each_transform_equals_pillow(sp, h, w):
     assert np.array_equal(sp.sharpen(hc).cpu().numpy(), want_sh)
 
 
+@pytest.mark.parametrize("lo,n_hi,n", [(100, 32, 64), (100, 31, 64), (100, 33, 64), (0, 1, 2), (254, 1, 2), (17, 4999, 9998),
+                                      (17, 4998, 9998), (200, 1 << 19, 1 << 20)])
+def test_contrast_mean_is_rounded_on_the_device_as_pillow_rounds_it(sp, lo, n_hi, n):
+    """The mean of ImageEnhance.Contrast is int(mean(L) + 0.5); the device takes it from the luma sum without a host round trip
+    (hwocr_img_contrast_dev).  Gray pages whose mean sits on, just below and just above a .5 boundary, against Pillow, and the
+    host-mean entry point on the same mean: identical bytes."""
+    from handwritten_ocr_amd import _lib
+
+    w = 64 if n % 64 == 0 else 2
+    g = np.full(n, lo, np.uint8)
+    g[:n_hi] = lo + 1
+    arr = np.ascontiguousarray(np.repeat(g.reshape(n // w, w, 1), 3, axis=2))
+    im = Image.fromarray(arr, "RGB")
+    want = np.asarray(ImageEnhance.Contrast(im).enhance(2.0))
+    dev = torch.from_numpy(arr).cuda()
+    got = sp.high_contrast(dev)
+    assert np.array_equal(got.cpu().numpy(), want)
+    mean = int(int(sp._sum.item()) / n + 0.5)
+    assert mean == int(np.asarray(im.convert("L"), np.int64).sum() / n + 0.5)
+    out = torch.empty_like(dev)
+    _lib.check(sp.lib.hwocr_img_contrast(_lib.ptr(dev), _lib.ptr(out), 3 * n, mean, 2.0, _lib.stream_handle()), "hwocr_img_contrast")
+    assert torch.equal(out, got)
+
+
 @pytest.mark.parametrize("h,w,oh,ow", [(37, 53, 56, 84), (300, 420, 280, 392), (1024, 1024, 1008, 1008), (1024, 1024, 896, 896),
                                        (200, 200, 504, 504)])
 def test_resize_equals_pillow_bicubic(sp, h, w, oh, ow):
