@@ -123,6 +123,10 @@ _HIP_SIGS = {
     "hwocr_gemm_rows16": ([P, I, P, P, I, I, I, I, I, I, C.POINTER(Rows16Norm), P], I),
     "hwocr_gemm_skinny_variant": ([I, I, I, I, I, I, C.c_char_p, I], I),
     "hwocr_attn_decode_variant": ([I, I, I, C.c_char_p, I], I),
+    "hwocr_stream_create_cumask": ([P, I, C.POINTER(C.c_void_p)], I),
+    "hwocr_stream_destroy": ([P], I),
+    "hwocr_set_cu_budget": ([I], I),
+    "hwocr_probe_placement": ([P, I, L, P], I),
     "hwocr_plan_begin": ([], I),
     "hwocr_plan_end": ([C.c_char_p, I, C.POINTER(I)], I),
     "hwocr_tile_weights": ([P, P, I, I, I, P], I),

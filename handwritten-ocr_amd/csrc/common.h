@@ -72,6 +72,9 @@ static inline int hwocr_launch_status_at(const char* where) {
 }
 #define hwocr_launch_status() hwocr_launch_status_at(__func__)
 
+// CUs the calling thread's launches may count on (hwocr_set_cu_budget, runtime.hip); 0 = the whole device
+int hwocr_cu_budget();
+
 // Plan recording (hwocr_plan_begin / hwocr_plan_end, runtime.hip): while it is on for the calling thread every launcher
 // validates its arguments as usual, notes the kernel instance and geometry it WOULD launch and returns HWOCR_OK without touching
 // the device.  hwocr_vit_forward / hwocr_prefill run under it with placeholder pointers give the launch list of a configuration —

@@ -538,8 +538,9 @@ inline int persistent_grid(const WideArgs& b) {
       n = 256;
     return n;
   }();
-  const int ntiles = b.tilesM * b.tilesN;
-  return ntiles < cus ? ntiles : cus;
+  const int ntiles = b.tilesM * b.tilesN, budget = hwocr_cu_budget();
+  const int n = budget > 0 && budget < cus ? budget : cus;  // a CU-masked stream: one workgroup per CU it may use
+  return ntiles < n ? ntiles : n;
 }
 
 template <int EPI, bool STAGGER, bool FP8>

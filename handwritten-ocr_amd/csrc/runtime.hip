@@ -102,6 +102,51 @@ extern "C" int hwocr_plan_end(char* buf, int len, int* needed) {
   return HWOCR_OK;
 }
 
+// ---- partitioning the chip between streams (pipeline.py: one batch's tower + prefill beside another batch's decode)
+// A stream whose queue may only use the CUs of `mask` (bit i = CU i in the driver's enumeration; on gfx942 / gfx950 the kernel driver
+// deals consecutive bits round-robin over the 8 XCDs, so a prefix of n bits is n / 8 CUs of EVERY XCD and the XCD-aware tile mappings
+// keep their meaning - hwocr_probe_placement shows what a mask really gives).
+extern "C" int hwocr_stream_create_cumask(const unsigned int* mask, int words, void** stream_out) {
+  if (!mask || words <= 0 || !stream_out) return HWOCR_EINVAL;
+  (void)hipGetLastError();
+  hipStream_t s = nullptr;
+  if (hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask) != hipSuccess) return hwocr_launch_status();
+  *stream_out = s;
+  return HWOCR_OK;
+}
+extern "C" int hwocr_stream_destroy(void* stream) {
+  if (!stream) return HWOCR_EINVAL;
+  (void)hipGetLastError();
+  if (hipStreamDestroy((hipStream_t)stream) != hipSuccess) return hwocr_launch_status();
+  return HWOCR_OK;
+}
+// The CUs the calling thread's launches may count on (0 = the whole device): persistent kernels size their grid to it, so that a
+// launch into a CU-masked stream is one round of workgroups and not one and a third.
+static thread_local int t_cu_budget = 0;
+int hwocr_cu_budget() { return t_cu_budget; }
+extern "C" int hwocr_set_cu_budget(int cus) {
+  if (cus < 0) return HWOCR_EINVAL;
+  t_cu_budget = cus;
+  return HWOCR_OK;
+}
+namespace {
+__global__ __launch_bounds__(64) void probe_placement_kernel(unsigned int* out, long spin) {
+  const long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+    out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: cu [11:8], sh [12], se [15:13]
+  }
+}
+}  // namespace
+// out[n_wg][2] = (XCC_ID, HW_ID) of the CU each of n_wg one-wave workgroups ran on; each holds its CU for spin_cycles
+extern "C" int hwocr_probe_placement(unsigned int* out, int n_wg, long spin_cycles, hipStream_t st) {
+  if (!out || n_wg <= 0 || spin_cycles < 0) return HWOCR_EINVAL;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(probe_placement_kernel, dim3(n_wg), dim3(64), 0, st, out, spin_cycles);
+  return hwocr_launch_status();
+}
+
 static char g_last_error[256] = "";
 extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text) {
   snprintf(g_last_error, sizeof(g_last_error), "%s: HIP error %d (%s)", where, hip_error, text ? text : "?");

@@ -1087,6 +1087,7 @@ class ReadEngine:
         mark("prefill")
         if hooks is not None:   # ... and its decode for the previous batch's decode
             hooks.prefill_end()
+            st = _lib.stream_handle()  # (a "partition" pipeline moves the decode onto its own CU-masked stream here)
         if return_logits:
             step_logits.append(torch.cat(first_logits, dim=0))
         def feed(col):  # teacher forcing: the fed token replaces the chosen one (the select kernel adds what it was fed

@@ -351,6 +351,15 @@ int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwoc
 int hwocr_plan_begin(void);
 int hwocr_plan_end(char* buf, int len, int* needed);
 
+/* Partitioning the chip between streams (pipeline.LanePipeline, order "partition"): a stream whose queue may use only the CUs whose
+ * bit is set in mask[words] (hipExtStreamCreateWithCUMask; consecutive bits are dealt round-robin over the XCDs by the driver), the
+ * number of CUs the calling thread's persistent launches should size their grids to (0 = whole device), and a probe that reports
+ * where n_wg one-wave workgroups ran: out[n_wg][2] = (XCC_ID, HW_ID) hardware registers. */
+int hwocr_stream_create_cumask(const unsigned int* mask, int words, void** stream_out);
+int hwocr_stream_destroy(void* stream);
+int hwocr_set_cu_budget(int cus);
+int hwocr_probe_placement(unsigned int* out, int n_wg, long spin_cycles, hwocr_stream_t stream);
+
 /* capture one decode step into a HIP graph; replay it n times back-to-back on `stream` */
 int hwocr_decode_graph_create(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
                               const hwocr_gen_state* st, int nseq, int attn_splits, void** graph_out);

@@ -74,3 +74,57 @@ def test_a_failing_batch_raises_and_the_pipeline_survives(setup):
     torch.cuda.synchronize()
     want = eng.generate(p, q, max_new=4, min_new=4)
     assert pipe.run([ok, ok, ok]) == [want] * 3
+
+
+def test_a_cu_masked_stream_runs_where_its_mask_says_and_computes_the_same():
+    """hwocr_stream_create_cumask (tools/bench_partition.py, DESIGN.md §3 - measured, not the default schedule): a prefix of 64 mask
+    bits is 8 CUs of every XCD, the complement the other 24; a persistent GEMM launched into the masked stream with the matching CU
+    budget returns the bytes of the same GEMM on the whole chip."""
+    import ctypes as C
+
+    from handwritten_ocr_amd import _lib
+
+    lib = _lib.hip()
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def stream(bits):
+        words = (C.c_uint * 8)(*[sum(1 << b for b in range(32) if 32 * w + b in bits) for w in range(8)])
+        h = C.c_void_p()
+        _lib.check(lib.hwocr_stream_create_cumask(words, 8, C.byref(h)), "hwocr_stream_create_cumask")
+        return torch.cuda.ExternalStream(h.value), h
+
+    def where(s):
+        out = torch.zeros(4096, 2, dtype=torch.int32, device="cuda")
+        with torch.cuda.stream(s):
+            _lib.check(lib.hwocr_probe_placement(_lib.ptr(out), 4096, 40000, _lib.stream_handle()), "hwocr_probe_placement")
+            s.synchronize()
+        o = out.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        per = {}
+        for x, c in zip((o[:, 0] & 0xF).tolist(), ((o[:, 1] >> 8) & 0xFF).tolist()):  # XCC_ID; HW_ID cu [11:8] sh [12] se [15:13]
+            per.setdefault(x, set()).add(c)
+        return {x: len(v) for x, v in per.items()}
+
+    small, hs = stream(set(range(64)))
+    big, hb = stream(set(range(64, ncu)))
+    try:
+        assert where(small) == {x: 8 for x in range(8)}
+        assert where(big) == {x: (ncu - 64) // 8 for x in range(8)}
+        g = torch.Generator(device="cuda").manual_seed(3)
+        M, N, K = 4096, 1280, 1280
+        X = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+        W = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).bfloat16()
+        want, got = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.hwocr_gemm_wide(_lib.ptr(X), _lib.ptr(W), None, None, _lib.ptr(want), M, N, K, K, K, N, 0, 0, _lib.stream_handle()))
+        torch.cuda.synchronize()
+        assert lib.hwocr_set_cu_budget(ncu - 64) == 0
+        try:
+            with torch.cuda.stream(big):
+                _lib.check(lib.hwocr_gemm_wide(_lib.ptr(X), _lib.ptr(W), None, None, _lib.ptr(got), M, N, K, K, K, N, 0, 0, _lib.stream_handle()))
+                big.synchronize()
+        finally:
+            lib.hwocr_set_cu_budget(0)
+        assert torch.equal(got, want)
+    finally:
+        torch.cuda.synchronize()
+        _lib.check(lib.hwocr_stream_destroy(hs), "hwocr_stream_destroy")
+        _lib.check(lib.hwocr_stream_destroy(hb), "hwocr_stream_destroy")

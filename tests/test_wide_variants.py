@@ -220,3 +220,27 @@ def test_plan_recording_launches_nothing_and_rejects_what_the_launchers_reject()
     assert lib.hwocr_plan_end(None, 0, C.byref(need)) == 1 and need.value == 1                        # nothing was noted
     buf = C.create_string_buffer(4)
     assert lib.hwocr_plan_end(buf, 4, C.byref(need)) == 0 and buf.value == b""
+
+
+def test_cu_budget_sizes_the_persistent_grid():
+    """hwocr_set_cu_budget (a thread's launches go into a CU-masked stream, tools/bench_partition.py): the persistent GEMM's grid
+    follows it, and only it; the arguments of the stream calls are checked before anything touches a device."""
+    lib = _lib.hip()
+    grid = lambda: int(_fields(_plan(lambda l: l.hwocr_gemm_wide(ONE, ONE, None, None, ONE, 62208, 1280, 1280, 1280, 1280, 1280, 0, 0,
+                                                                  None))[0])["grid"])  # noqa: E731
+    whole = grid()
+    assert whole >= 192
+    assert lib.hwocr_set_cu_budget(192) == 0
+    try:
+        assert grid() == 192
+        assert lib.hwocr_set_cu_budget(100000) == 0
+        assert grid() == whole
+    finally:
+        assert lib.hwocr_set_cu_budget(0) == 0
+    assert grid() == whole
+    assert lib.hwocr_set_cu_budget(-1) == 1
+    out = C.c_void_p()
+    assert lib.hwocr_stream_create_cumask(None, 8, C.byref(out)) == 1
+    assert lib.hwocr_stream_create_cumask((C.c_uint * 8)(), 0, C.byref(out)) == 1
+    assert lib.hwocr_stream_destroy(None) == 1
+    assert lib.hwocr_probe_placement(None, 4, 0, None) == 1
