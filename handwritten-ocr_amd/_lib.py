@@ -10,7 +10,8 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 11  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
+SELECT_WS_INTS = 40  # HWOCR_SELECT_WS_INTS
+ABI_VERSION = 12  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
 
 P = C.c_void_p
 I = C.c_int
@@ -95,8 +96,8 @@ class Kv(C.Structure):
 
 
 class DecWs(C.Structure):
-    _fields_ = [(n, P) for n in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "logits", "q8",
-                                  "q8s")]
+    _fields_ = [(n, P) for n in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "arrive", "select_ws", "logits",
+                                  "q8", "q8s")]
 
 
 class Rows16Norm(C.Structure):
@@ -133,8 +134,8 @@ _HIP_SIGS = {
     "hwocr_tile_weights_fp8": ([P, P, I, I, I, P], I),
     "hwocr_gemm_skinny_w8": ([P, P, P, P, P, I, I, I, I, I, I, I, P], I),
     "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, I, P], I),
-    "hwocr_attn_decode": ([P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, P], I),
-    "hwocr_attn_decode_qkv": ([P, I, L, P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, I, I, P, P], I),
+    "hwocr_attn_decode": ([P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, P], I),
+    "hwocr_attn_decode_qkv": ([P, I, L, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, I, I, P, P], I),
     "hwocr_attn_varlen": ([P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, F, P], I),
     "hwocr_patchify": ([P, P, P, I, I, I, I, I, I, I, I, P, P], I),
     "hwocr_layernorm": ([P, P, P, P, I, I, I, I, F, P], I),
@@ -144,7 +145,7 @@ _HIP_SIGS = {
     "hwocr_mrope_kv_prefill": ([P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, I, I, P], I),
     "hwocr_decode_qkv_finish": ([P, I, L, P, P, P, P, P, P, P, P, I, I, I, L, L, L, L, L, I, I, I, I, P, P], I),
     "hwocr_embed_splice": ([P, P, P, P, P, I, I, F, P], I),
-    "hwocr_argmax_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P, I, F, P], I),
+    "hwocr_argmax_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P, I, F, P, P], I),
     "hwocr_sample_advance": ([P, I, I, I, P, P, P, P, P, I, I, C.POINTER(I), I, I, P, I, F, F, I, F, C.c_ulonglong, P, P, P], I),
     "hwocr_vit_forward": ([C.POINTER(Vit), C.POINTER(VitWs), P, I, I, I, I, C.POINTER(VitLayout), P, P], I),
     "hwocr_prefill": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), P, P, P, P, P, P,

@@ -734,7 +734,46 @@ struct DecodeArgs {
   const bf16* bias = nullptr; const int* rope_delta = nullptr; const bf16* cos_tab = nullptr; const bf16* sin_tab = nullptr;
   int ctx = 0, max_pos = 0; int* status = nullptr;
   bf16* Kw = nullptr; bf16* VTw = nullptr;  // the caches again, writable
+  // nsplit > 1: one arrival counter per (read, kv head), zero between launches.  The workgroup that arrives last merges the
+  // partials itself (nullptr: attn_decode_merge_kernel does, in a launch of its own)
+  int* arrive = nullptr;
 };
+
+// partials of query head h of read b, output feature d: all <= 16 (m, l) pairs and output values are loaded up front (indices
+// clamped, never a branch around a load: the loads of a head's 16 splits are one round trip to L2, not sixteen) and then combined
+// in ascending split order - the same arithmetic whoever runs it (attn_decode_merge_kernel or the last workgroup of attn_decode_kernel)
+// DEVICE_SCOPE: the partials were written by workgroups of the SAME launch on other XCDs - read them with device-scope loads (sc1:
+// past this XCD's L2, which is not coherent with the others inside a launch)
+template <int DEC_HD, bool DEVICE_SCOPE>
+__device__ __forceinline__ void merge_splits(const DecodeArgs& a, int b, int h, int d) {
+  auto ld = [](const float* p) {
+    if constexpr (DEVICE_SCOPE) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+  };
+  const int hk = h / a.G, qq = h - hk * a.G;
+  const long base = ((long)b * a.Hkv + hk) * a.nsplit * a.G + qq;
+  float m[16], l[16], o[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const long e = base + (long)(s < a.nsplit ? s : 0) * a.G;
+    m[s] = ld(a.part_ml + e * 2);
+    l[s] = ld(a.part_ml + e * 2 + 1);
+    o[s] = ld(a.part_o + e * DEC_HD + d);
+  }
+  float M = NEG_BIG;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) M = s < a.nsplit ? fmaxf(M, m[s]) : M;
+  float L = 0.f, O = 0.f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    if (s < a.nsplit) {
+      const float f = exp2f(m[s] - M);
+      L += l[s] * f;
+      O += o[s] * f;
+    }
+  }
+  a.out[((long)b * a.Hq + h) * DEC_HD + d] = f2bf(O / L);
+}
 
 
 // Keys are walked in blocks of 32.  MFMA tile rows are assigned to keys so that the score registers a lane ends up with
@@ -941,43 +980,45 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
       a.out[((long)b * a.Hq + hk * a.G + qq) * DEC_HD + d] = f2bf(O / L);
     } else {
       const long base = (((long)b * a.Hkv + hk) * a.nsplit + split) * a.G;
-      a.part_o[(base + qq) * DEC_HD + d] = O;
-      if (d == 0) { a.part_ml[(base + qq) * 2] = M; a.part_ml[(base + qq) * 2 + 1] = L; }
+      if (a.arrive) {  // device-scope stores (sc1): visible to the merging workgroup on another XCD without flushing this XCD's L2
+        __hip_atomic_store(a.part_o + (base + qq) * DEC_HD + d, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == 0) {
+          __hip_atomic_store(a.part_ml + (base + qq) * 2, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(a.part_ml + (base + qq) * 2 + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        a.part_o[(base + qq) * DEC_HD + d] = O;
+        if (d == 0) { a.part_ml[(base + qq) * 2] = M; a.part_ml[(base + qq) * 2 + 1] = L; }
+      }
+    }
+  }
+  if constexpr (WAVES == 4) {
+    if (a.nsplit > 1 && a.arrive) {
+      // The workgroup of this (read, kv head) that arrives LAST merges the partials of its G query heads: no second launch (a merge
+      // launch was 6.7 us of a 3-read decode layer's 48).  The other splits ran on other XCDs, whose L2s are not coherent with this
+      // one inside a launch: partials are stored and loaded at device scope (sc1), every wave has waited for its stores before the
+      // barrier, and the count itself is a device-scope atomic.  (A __threadfence() per thread on either side - L2 write-back and
+      // invalidate - measured SLOWER than the merge launch: 1.63 against 1.48 ms per 3-read token.)  The counter goes back to zero
+      // for the next launch.
+      __shared__ int s_last;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) s_last = __hip_atomic_fetch_add(a.arrive + b * a.Hkv + hk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.nsplit - 1;
+      __syncthreads();
+      if (!s_last) return;
+      for (int idx = tid; idx < a.G * DEC_HD; idx += 64 * WAVES)
+        merge_splits<DEC_HD, true>(a, b, hk * a.G + idx / DEC_HD, idx % DEC_HD);
+      if (tid == 0) __hip_atomic_store(a.arrive + b * a.Hkv + hk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
-// One workgroup per (query head, read), one thread per output feature.  All <= 16 partial (m, l) pairs and output values of the
-// thread are loaded up front (indices clamped, never a branch around a load: the loads of a head's 16 splits are one round trip
-// to L2, not sixteen) and then combined in ascending split order — the arithmetic of the first form of this kernel, which walked
-// the splits in a loop of dependent loads from 6 workgroups and took 22 us of a 3-read decode layer's 70 (r03c profile).
+// One workgroup per (query head, read), one thread per output feature (merge_splits above; the first form of this kernel walked
+// the splits in a loop of dependent loads from 6 workgroups and took 22 us of a 3-read decode layer's 70, r03c profile).  Launched
+// only when the caller gives attn_decode_kernel no arrival counters.
 template <int DEC_HD>
 __global__ __launch_bounds__(DEC_HD) void attn_decode_merge_kernel(DecodeArgs a) {
-  const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-  const int hk = h / a.G, qq = h - hk * a.G;
-  const long base = ((long)b * a.Hkv + hk) * a.nsplit * a.G + qq;
-  float m[16], l[16], o[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const long e = base + (long)(s < a.nsplit ? s : 0) * a.G;
-    const f32x2 ml = *(const f32x2*)(a.part_ml + e * 2);
-    m[s] = ml[0];
-    l[s] = ml[1];
-    o[s] = a.part_o[e * DEC_HD + d];
-  }
-  float M = NEG_BIG;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) M = s < a.nsplit ? fmaxf(M, m[s]) : M;
-  float L = 0.f, O = 0.f;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    if (s < a.nsplit) {
-      const float f = exp2f(m[s] - M);
-      L += l[s] * f;
-      O += o[s] * f;
-    }
-  }
-  a.out[((long)b * a.Hq + h) * DEC_HD + d] = f2bf(O / L);
+  merge_splits<DEC_HD, false>(a, blockIdx.y, blockIdx.x, threadIdx.x);
 }
 
 }  // namespace
@@ -1045,10 +1086,10 @@ namespace {
 int launch_attn_decode(const DecodeArgs& a, int nseq, int head_dim, hipStream_t stream) {
   const int Hkv = a.Hkv, nsplit = a.nsplit;
   HWOCR_PLAN("attn_decode_kernel<%s,%d,%d>%s fused_qkv=%d nseq=%d Hq=%d Hkv=%d nsplit=%d nslab=%d", a.kv_tiled ? "tiled" : "rows",
-             (head_dim == 256 || nsplit > 1) ? 4 : 8, head_dim, nsplit > 1 ? "+merge" : "", a.slabs != nullptr, nseq, a.Hq, Hkv, nsplit, a.nslab);
+             (head_dim == 256 || nsplit > 1) ? 4 : 8, head_dim, nsplit > 1 ? (a.arrive ? "+lastwg" : "+merge") : "", a.slabs != nullptr, nseq, a.Hq, Hkv, nsplit, a.nslab);
   if (head_dim == 256) {  // 4 waves; a single pass when the caller asks for no split
     hipLaunchKernelGGL((attn_decode_kernel<false, 4, 256>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
-    if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<256>, dim3(a.Hq, nseq), dim3(256), 0, stream, a);
+    if (nsplit > 1 && !a.arrive) hipLaunchKernelGGL(attn_decode_merge_kernel<256>, dim3(a.Hq, nseq), dim3(256), 0, stream, a);
     return hwocr_launch_status();
   }
   if (nsplit == 1) {
@@ -1059,7 +1100,7 @@ int launch_attn_decode(const DecodeArgs& a, int nseq, int head_dim, hipStream_t 
   } else {
     hipLaunchKernelGGL((attn_decode_kernel<false, 4, 128>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
   }
-  if (nsplit > 1) hipLaunchKernelGGL(attn_decode_merge_kernel<128>, dim3(a.Hq, nseq), dim3(128), 0, stream, a);
+  if (nsplit > 1 && !a.arrive) hipLaunchKernelGGL(attn_decode_merge_kernel<128>, dim3(a.Hq, nseq), dim3(128), 0, stream, a);
   return hwocr_launch_status();
 }
 bool attn_decode_args_ok(int nseq, int Hq, int Hkv, int nsplit, float* part_o, float* part_ml, long k_seq, long k_head,
@@ -1075,7 +1116,7 @@ bool attn_decode_args_ok(int nseq, int Hq, int Hkv, int nsplit, float* part_o, f
 }  // namespace
 
 extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out,
-                                 float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit,
+                                 float* part_o, float* part_ml, int* arrive, int nseq, int Hq, int Hkv, int nsplit,
                                  long k_seq, long k_head, long v_seq, long v_head, long v_row, float scale,
                                  int head_dim, int kv_tiled, hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
@@ -1083,13 +1124,14 @@ extern "C" int hwocr_attn_decode(const void* Q, const void* K, const void* VT, c
     return HWOCR_EINVAL;
   DecodeArgs a{(const bf16*)Q, (const bf16*)K, (const bf16*)VT, lens, part_o, part_ml, (bf16*)out,
                k_seq, k_head, v_seq, v_head, v_row, Hq, Hkv, Hq / Hkv, nsplit, scale * 1.4426950408889634f, kv_tiled};
+  a.arrive = arrive;
   return launch_attn_decode(a, nseq, head_dim, stream);
 }
 
 // hwocr_decode_qkv_finish + hwocr_attn_decode in one launch (hwocr.h)
 extern "C" int hwocr_attn_decode_qkv(const float* slabs, int nslab, long slab_stride, const void* bias, void* K, void* VT,
                                      const int* lens, const int* rope_delta, const void* cos_tab, const void* sin_tab, void* out,
-                                     float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq,
+                                     float* part_o, float* part_ml, int* arrive, int nseq, int Hq, int Hkv, int nsplit, long k_seq,
                                      long k_head, long v_seq, long v_head, long v_row, float scale, int head_dim, int kv_tiled,
                                      int ctx, int max_pos, int* status, hipStream_t stream) {
   (void)hipGetLastError();
@@ -1100,7 +1142,7 @@ extern "C" int hwocr_attn_decode_qkv(const float* slabs, int nslab, long slab_st
                k_seq, k_head, v_seq, v_head, v_row, Hq, Hkv, Hq / Hkv, nsplit, scale * 1.4426950408889634f, kv_tiled};
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = slab_stride; a.bias = (const bf16*)bias; a.rope_delta = rope_delta;
   a.cos_tab = (const bf16*)cos_tab; a.sin_tab = (const bf16*)sin_tab; a.ctx = ctx; a.max_pos = max_pos; a.status = status;
-  a.Kw = (bf16*)K; a.VTw = (bf16*)VT;
+  a.Kw = (bf16*)K; a.VTw = (bf16*)VT; a.arrive = arrive;
   return launch_attn_decode(a, nseq, head_dim, stream);
 }
 

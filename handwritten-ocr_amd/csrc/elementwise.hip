@@ -532,13 +532,20 @@ struct SelectArgs {
   int* cur_ids; int* lens; int* n_gen; int* finished; int* out_tokens; int max_new, min_new;
   int eos[4]; int n_eos; int pad_id;
   unsigned* seen; int seen_ld; float rep_penalty;  // bitmap [nseq][seen_ld words] of ids in prompt + output so far, or NULL
+  int* split_ws = nullptr;                         // argmax_advance_kernel<., PARTS > 1>
 };
 // One workgroup of 16 waves per read: a row is V x 2 B (300 KB at V = 151936) and only `nseq` CUs take part, so what
 // matters is loads in flight per CU — 4 independent 16-byte loads per thread per trip (256 threads, one load per trip:
 // 95 us per step at 126 reads).
+// PARTS > 1 (few reads in flight: one workgroup per read leaves the chip empty and took 37 us of a 3-read step's 1480): the row is
+// cut into PARTS contiguous ranges, one workgroup of NT threads each; every workgroup leaves its (maximum, index) in a.split_ws and
+// the one that arrives last picks the winner and does the bookkeeping.  (value, lower index) is a total order, so the pick does not
+// depend on how the row was cut: the same token as the one-workgroup form.
 constexpr int ARG_THREADS = 1024;
-__global__ __launch_bounds__(ARG_THREADS) void argmax_advance_kernel(SelectArgs a) {
-  constexpr int NW = ARG_THREADS / 64;
+constexpr int SEL_PARTS = 16, SEL_WS_INTS = 40;  // split_ws per read: [0] arrivals, [1 + 2 part] = (value bits, index); hwocr.h
+template <int NT, int PARTS>
+__global__ __launch_bounds__(NT) void argmax_advance_kernel(SelectArgs a) {
+  constexpr int NW = NT / 64;
   __shared__ float s_val[NW];
   __shared__ int s_idx[NW];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -551,16 +558,20 @@ __global__ __launch_bounds__(ARG_THREADS) void argmax_advance_kernel(SelectArgs 
   // already in input_ids), on the fp32 copy of the logits like every processor
   // The token fed to produce these logits (cur_ids: the previous pick, or the teacher-forced one the host wrote) joins the
   // bitmap first; the prompt's ids were put there by the host, and the call that follows a prefill has n_gen == 0.
-  if (a.seen) {
-    if (tid == 0 && a.n_gen[b] > 0 && !a.finished[b]) {
-      const int t = a.cur_ids[b];
-      if (t >= 0 && t < a.V) a.seen[(long)b * a.seen_ld + (t >> 5)] |= 1u << (t & 31);
-    }
+  // (PARTS > 1: the workgroups of a read treat the fed token as seen while they scan; the finishing one records it.)
+  int fed = -1;
+  if (a.seen && a.n_gen[b] > 0 && !a.finished[b]) {
+    const int t = a.cur_ids[b];
+    if (t >= 0 && t < a.V) fed = t;
+  }
+  if (PARTS == 1 && a.seen) {
+    if (tid == 0 && fed >= 0) a.seen[(long)b * a.seen_ld + (fed >> 5)] |= 1u << (fed & 31);
     __syncthreads();
   }
   const unsigned* seen = a.seen ? a.seen + (long)b * a.seen_ld : nullptr;
   auto take = [&](const bf16x8& v, int ch) {
-    const unsigned bits = seen ? (seen[ch >> 2] >> ((ch & 3) * 8)) & 0xffu : 0u;  // the 8 ids of this chunk
+    unsigned bits = seen ? (seen[ch >> 2] >> ((ch & 3) * 8)) & 0xffu : 0u;  // the 8 ids of this chunk
+    if (PARTS > 1 && (fed >> 3) == ch) bits |= 1u << (fed & 7);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float x = bf2f(v[e]);
@@ -572,15 +583,17 @@ __global__ __launch_bounds__(ARG_THREADS) void argmax_advance_kernel(SelectArgs 
       if (x > best || (x == best && idx < bi)) { best = x; bi = idx; }
     }
   };
-  int ch = tid;
-  for (; ch + 3 * ARG_THREADS < nch; ch += 4 * ARG_THREADS) {
+  const int per = (nch + PARTS - 1) / PARTS;
+  const int c0 = PARTS > 1 ? (int)blockIdx.y * per : 0, c1 = PARTS > 1 ? min(nch, c0 + per) : nch;
+  int ch = c0 + tid;
+  for (; ch + 3 * NT < c1; ch += 4 * NT) {
     bf16x8 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8*)(row + (long)(ch + u * ARG_THREADS) * 8);
+    for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8*)(row + (long)(ch + u * NT) * 8);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) take(v[u], ch + u * ARG_THREADS);
+    for (int u = 0; u < 4; ++u) take(v[u], ch + u * NT);
   }
-  for (; ch < nch; ch += ARG_THREADS) take(*(const bf16x8*)(row + (long)ch * 8), ch);
+  for (; ch < c1; ch += NT) take(*(const bf16x8*)(row + (long)ch * 8), ch);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(best, o);
@@ -592,6 +605,29 @@ __global__ __launch_bounds__(ARG_THREADS) void argmax_advance_kernel(SelectArgs 
   if (tid == 0) {
     for (int k = 1; k < NW; ++k)
       if (s_val[k] > best || (s_val[k] == best && s_idx[k] < bi)) { best = s_val[k]; bi = s_idx[k]; }
+    if (PARTS > 1) {
+      // device-scope (sc1) stores / loads around a device-scope count, as in attn_decode_kernel: the other parts ran on other XCDs
+      int* ws = a.split_ws + (long)b * SEL_WS_INTS;
+      __hip_atomic_store(ws + 1 + 2 * blockIdx.y, __float_as_int(best), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ws + 2 + 2 * blockIdx.y, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (__hip_atomic_fetch_add(ws, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != PARTS - 1) return;
+      int pv[PARTS], pi[PARTS];
+#pragma unroll
+      for (int k = 0; k < PARTS; ++k) {
+        pv[k] = __hip_atomic_load(ws + 1 + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pi[k] = __hip_atomic_load(ws + 2 + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      best = -INFINITY;
+      bi = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < PARTS; ++k) {
+        const float v = __int_as_float(pv[k]);
+        if (v > best || (v == best && pi[k] < bi)) { best = v; bi = pi[k]; }
+      }
+      __hip_atomic_store(ws, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (fed >= 0) a.seen[(long)b * a.seen_ld + (fed >> 5)] |= 1u << (fed & 31);
+    }
     int tok = bi;
     if (a.finished[b]) {
       tok = a.pad_id;
@@ -1119,16 +1155,23 @@ extern "C" int hwocr_embed_splice(const int* ids, const int* img_row, const void
 
 extern "C" int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_ids, int* lens, int* n_gen,
                                     int* finished, int* out_tokens, int max_new, int min_new, const int* eos,
-                                    int n_eos, int pad_id, unsigned* seen, int seen_ld, float rep_penalty,
+                                    int n_eos, int pad_id, unsigned* seen, int seen_ld, float rep_penalty, int* split_ws,
                                     hipStream_t stream) {
   (void)hipGetLastError();  // drop stale status left by other HIP users of this thread (e.g. event queries)
   if (nseq <= 0 || V % 8 || ldl % 8 || n_eos < 0 || n_eos > 4) return HWOCR_EINVAL;
   if (seen && (seen_ld * 32 < V || !(rep_penalty > 0.f))) return HWOCR_EINVAL;
   SelectArgs a{(const bf16*)logits, ldl, V, cur_ids, lens, n_gen, finished, out_tokens, max_new, min_new,
                {0, 0, 0, 0}, n_eos, pad_id, (seen && rep_penalty != 1.0f) ? seen : nullptr, seen_ld, rep_penalty};
-  HWOCR_PLAN("argmax_advance_kernel nseq=%d V=%d penalty=%d", nseq, V, a.seen != nullptr);
+  static_assert(SEL_WS_INTS == HWOCR_SELECT_WS_INTS && 1 + 2 * SEL_PARTS <= SEL_WS_INTS, "hwocr.h: split_ws ints per read");
+  const bool split = split_ws && nseq <= 16 && V >= 8 * 256 * SEL_PARTS;  // few reads, a row worth cutting
+  HWOCR_PLAN("argmax_advance_kernel<%s> nseq=%d V=%d penalty=%d", split ? "256,16" : "1024,1", nseq, V, a.seen != nullptr);
   for (int k = 0; k < n_eos; ++k) a.eos[k] = eos[k];
-  hipLaunchKernelGGL(argmax_advance_kernel, dim3(nseq), dim3(ARG_THREADS), 0, stream, a);
+  if (split) {
+    a.split_ws = split_ws;
+    hipLaunchKernelGGL((argmax_advance_kernel<256, SEL_PARTS>), dim3(nseq, SEL_PARTS), dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((argmax_advance_kernel<ARG_THREADS, 1>), dim3(nseq), dim3(ARG_THREADS), 0, stream, a);
+  }
   return hwocr_launch_status();
 }
 

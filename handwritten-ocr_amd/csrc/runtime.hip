@@ -309,7 +309,8 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
   CHECK(hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids + seq0, gs->lens + seq0,
                              gs->n_gen + seq0, gs->finished + seq0, gs->out_tokens + (long)seq0 * gs->max_new,
                              gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id,
-                             gs->seen ? gs->seen + (long)seq0 * gs->seen_ld : nullptr, gs->seen_ld, gs->rep_penalty, st));
+                             gs->seen ? gs->seen + (long)seq0 * gs->seen_ld : nullptr, gs->seen_ld, gs->rep_penalty,
+                             ws->select_ws, st));  // (a prefill chunk's rows use the first nseq counters: the stream orders the chunks)
   return HWOCR_OK;
 }
 
@@ -325,6 +326,12 @@ static void decode_splits(const hwocr_decoder* m, int nseq, int& s_qkv, int& s_o
   s_d = stream ? pick_splitk_stream(m->inter, Hd, nseq) : pick_splitk(m->inter, Hd, 400);
 }
 
+// HWOCR_DECODE_LASTWG=0: split attention partials are merged, and the token picked, by launches of their own (A/B runs)
+static bool decode_lastwg() {
+  static const bool on = [] { const char* e = getenv("HWOCR_DECODE_LASTWG"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 // the token selection that ends a decode step: logits -> next token, stop flags, bookkeeping (all on the device)
 static int decode_select(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_gen_state* gs, int nseq, hipStream_t st) {
   if (gs->do_sample) {
@@ -335,7 +342,7 @@ static int decode_select(const hwocr_decoder* m, const hwocr_dec_ws* ws, const h
   }
   return hwocr_argmax_advance(ws->logits, m->vocab, m->vocab, nseq, gs->cur_ids, gs->lens, gs->n_gen, gs->finished,
                               gs->out_tokens, gs->max_new, gs->min_new, gs->eos, gs->n_eos, gs->pad_id, gs->seen, gs->seen_ld,
-                              gs->rep_penalty, st);
+                              gs->rep_penalty, decode_lastwg() ? ws->select_ws : nullptr, st);
 }
 
 // <= 16 reads in flight and every layer GEMM with its bf16 fragment-tiled copy (no E4M3 decode weights): the 6-launch layer of
@@ -389,7 +396,7 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
       // the QKV projection leaves ONE fp32 slab (in ws->qkv: ws->slabs still holds the down projection's) for the attention launch
       CHECK(hwocr_gemm_rows16(nullptr, 0, L.qkv_wt, ws->qkv, QW, nseq, QW, Hd, HWOCR_EPI_PARTIAL, 1, &n1, st));
       CHECK(hwocr_attn_decode_qkv((const float*)ws->qkv, 1, (long)nseq * QW, L.qkv_b, Kc, Vc, gs->lens, gs->rope_delta, m->rope_cos,
-                                  m->rope_sin, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv, attn_splits, k_seq, k_head,
+                                  m->rope_sin, ws->attn, ws->part_o, ws->part_ml, decode_lastwg() ? ws->arrive : nullptr, nseq, m->Hq, m->Hkv, attn_splits, k_seq, k_head,
                                   k_seq, k_head, kv->ctx, scale, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
       CHECK(hwocr_gemm_rows16(ws->attn, OW, L.o_wt, hbuf[cur], Hd, nseq, Hd, OW, HWOCR_EPI_RESIDUAL, 1, nullptr, st));
       hwocr_rows16_norm n2{hbuf[cur], nullptr, Hd, nullptr, 0, 0, 0, L.post_norm_w, m->eps, G};
@@ -418,11 +425,11 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
       CHECK(hwocr_decode_qkv_finish(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, ws->q, Kc, Vc, gs->lens, gs->rope_delta,
                                     m->rope_cos, m->rope_sin, nseq, m->Hq, m->Hkv, k_seq, k_head, k_seq, k_head,
                                     kv->ctx, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
-      CHECK(hwocr_attn_decode(ws->q, Kc, Vc, gs->lens, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv,
+      CHECK(hwocr_attn_decode(ws->q, Kc, Vc, gs->lens, ws->attn, ws->part_o, ws->part_ml, decode_lastwg() ? ws->arrive : nullptr, nseq, m->Hq, m->Hkv,
                               attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, HD, kv->tiled, st));
     } else
     CHECK(hwocr_attn_decode_qkv(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, Kc, Vc, gs->lens, gs->rope_delta, m->rope_cos,
-                                m->rope_sin, ws->attn, ws->part_o, ws->part_ml, nseq, m->Hq, m->Hkv, attn_splits, k_seq, k_head,
+                                m->rope_sin, ws->attn, ws->part_o, ws->part_ml, decode_lastwg() ? ws->arrive : nullptr, nseq, m->Hq, m->Hkv, attn_splits, k_seq, k_head,
                                 k_seq, k_head, kv->ctx, scale, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
     CHECK(decode_gemm(ws->attn, L.o_w, L.o_wt, L.o8t, L.o8.scale, ws->slabs, nseq, Hd, OW, Hd, HWOCR_EPI_PARTIAL, s_o, st));
     CHECK(hwocr_add_rmsnorm(ws->slabs, s_o, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd,

@@ -397,7 +397,7 @@ def decode_plan(cfg: ModelConfig, reads: int, fp8: bool = False, attn_splits: in
         dec.lm_head8t = _lib.W8(w=one, scale=one)
     else:
         dec.lm_head_t = one
-    ws = _lib.DecWs(**{k: one for k in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "logits")})
+    ws = _lib.DecWs(**{k: one for k in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "arrive", "select_ws", "logits")})
     kv = _lib.Kv(k=one, vt=one, nseq_max=max(reads, 1), ctx=2048, tiled=1 if cfg.head_dim == 128 else 0)
     eos = (C.c_int * 4)(0, 0, 0, 0)
     gs = _lib.GenState(cur_ids=one, lens=one, n_gen=one, finished=one, out_tokens=one, rope_delta=one, max_new=8, min_new=0, n_eos=1,
@@ -479,7 +479,7 @@ def wide_plan(cfg: ModelConfig, hw: tuple[int, int], pages: int, reads: int, pro
     dec = _lib.Decoder(layers=cfg.layers, hidden=cfg.hidden, Hq=cfg.q_heads, Hkv=cfg.kv_heads, inter=cfg.inter, vocab=cfg.vocab,
                        sec0=16, sec1=40, head_dim=HD, gemma=1 if pg else 0, eps=cfg.eps, embed_scale=1.0, embed=one, lm_head=one,
                        lm_head_t=one, final_norm_w=one, L=layers, rope_cos=one, rope_sin=one, max_pos=4096)
-    dws = _lib.DecWs(**{k: one for k in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "logits")})
+    dws = _lib.DecWs(**{k: one for k in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "arrive", "select_ws", "logits")})
     if fp8:
         dws.q8, dws.q8s = one, one
     Tp = _ceil(prompt_len, 64)
@@ -819,6 +819,9 @@ class ReadEngine:
                 slabs=torch.empty(slab_elems, dtype=torch.float32, device=dev),
                 part_o=torch.empty(R * c.q_heads * splits * HD, dtype=torch.float32, device=dev),
                 part_ml=torch.empty(R * c.q_heads * splits * 2, dtype=torch.float32, device=dev),
+                # arrival counters of the split decode attention / the split token selection: zero here, left zero by every launch
+                arrive=torch.zeros(R * c.kv_heads, dtype=torch.int32, device=dev),
+                select_ws=torch.zeros(R * _lib.SELECT_WS_INTS, dtype=torch.int32, device=dev),
                 logits=torch.empty(R, c.vocab, dtype=bf, device=dev))
             if self.fp8:  # E4M3 staging of one prefill GEMM input + its row scales
                 self._bufs["q8"] = torch.empty(rows * max(c.hidden, c.q_heads * HD, c.inter), dtype=torch.uint8, device=dev)

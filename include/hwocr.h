@@ -38,7 +38,7 @@ typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
 #define HWOCR_EPI_GELU_TANH 6 /* nn.GELU(approximate="tanh"): SigLIP MLP (HF siglip/modeling_siglip.py:310-322) */
 #define HWOCR_EPI_GEGLU 7     /* SWIGLU's interleaved tile pairs with the tanh GELU as gate: Gemma MLP (HF gemma/modeling_gemma.py:84-97) */
 
-#define HWOCR_ABI_VERSION 11 /* bumped whenever a signature or struct layout below changes */
+#define HWOCR_ABI_VERSION 12 /* bumped whenever a signature or struct layout below changes */
 int hwocr_abi_version(void);
 /* text of the most recent launch failure in this process ("" if none): launcher name + HIP error */
 const char* hwocr_last_error(void);
@@ -127,9 +127,12 @@ int hwocr_attn_varlen(const void* Q, const void* K, const void* VT, void* O, con
 
 /* One query token per read against its KV cache (HF modeling_qwen2_vl.py:553-569 with q_len == 1).  head_dim 128, or 256
  * (Gemma) with the row layout only.  kv_tiled (here and in the cache writers below): the cache is in the fragment-tiled
- * layout, strides k_row/v_row unused.  1 <= nsplit <= 16 (part_o / part_ml hold 16 splits). */
+ * layout, strides k_row/v_row unused.  1 <= nsplit <= 16 (part_o / part_ml hold 16 splits).  nsplit > 1: the key range of a
+ * (read, kv head) is split over nsplit workgroups whose partial results are merged — by the workgroup that arrives last, if
+ * `arrive` gives it one int32 counter per (read, kv head) [nseq * Hkv] that is ZERO when the call is made (the kernel leaves it
+ * zero), else (arrive == NULL) by a second launch.  Same arithmetic in the same order either way: identical bytes. */
 int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* lens, void* out, float* part_o,
-                      float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head, long v_seq,
+                      float* part_ml, int* arrive, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head, long v_seq,
                       long v_head, long v_row, float scale, int head_dim, int kv_tiled, hwocr_stream_t stream);
 
 /* hwocr_decode_qkv_finish (below) and hwocr_attn_decode in ONE launch: every (read, kv head) workgroup first sums the slabs of
@@ -138,7 +141,7 @@ int hwocr_attn_decode(const void* Q, const void* K, const void* VT, const int* l
  * the invariants of hwocr_decode_qkv_finish are skipped as there (no output, HWOCR_STATUS_BAD_POSITION raised in *status). */
 int hwocr_attn_decode_qkv(const float* slabs, int nslab, long slab_stride, const void* bias, void* K, void* VT,
                           const int* lens, const int* rope_delta, const void* cos_tab, const void* sin_tab, void* out,
-                          float* part_o, float* part_ml, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head,
+                          float* part_o, float* part_ml, int* arrive, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head,
                           long v_seq, long v_head, long v_row, float scale, int head_dim, int kv_tiled, int ctx, int max_pos,
                           int* status, hwocr_stream_t stream);
 
@@ -207,10 +210,14 @@ int hwocr_embed_splice(const int* ids, const int* img_row, const void* table, co
 /* seen (optional): bitmap [nseq][seen_ld 32-bit words] of the token ids already in a read's prompt + output; with
  * rep_penalty != 1 their fp32 scores are divided (positive) or multiplied (negative) by it before the argmax — HF
  * RepetitionPenaltyLogitsProcessor, which the Qwen2.5-VL / olmOCR generation configs switch on.  The caller fills in the
- * prompt's ids; every later call first adds the id it was fed (cur_ids on entry, when n_gen > 0) */
+ * prompt's ids; every later call first adds the id it was fed (cur_ids on entry, when n_gen > 0).
+ * split_ws (optional): device int32 [nseq][HWOCR_SELECT_WS_INTS] whose first int per read is ZERO when the call is made (the kernel
+ * leaves it zero).  With it and nseq <= 16 a row is scanned by 16 workgroups instead of one and the last to arrive finishes the read;
+ * the token picked is the same (maximum value, lowest index). */
+#define HWOCR_SELECT_WS_INTS 40
 int hwocr_argmax_advance(const void* logits, int ldl, int V, int nseq, int* cur_ids, int* lens, int* n_gen,
                          int* finished, int* out_tokens, int max_new, int min_new, const int* eos, int n_eos,
-                         int pad_id, unsigned* seen, int seen_ld, float rep_penalty, hwocr_stream_t stream);
+                         int pad_id, unsigned* seen, int seen_ld, float rep_penalty, int* split_ws, hwocr_stream_t stream);
 
 /* generate(do_sample=True): temperature -> top-k -> top-p -> one multinomial draw per read, then the same bookkeeping as
  * hwocr_argmax_advance (replaces HF generation/logits_process.py Temperature / TopK / TopP warpers and the softmax +
@@ -310,6 +317,8 @@ typedef struct {
   void *h, *hn, *qkv, *q, *attn, *act;   /* bf16 [rows][...] */
   float *slabs;                           /* fp32 split-K slabs (decode) */
   float *part_o, *part_ml;                /* decode attention partials */
+  int *arrive;                            /* [nseq_max][Hkv] arrival counters of hwocr_attn_decode, zero-initialised (or NULL: merge launch) */
+  int *select_ws;                         /* [nseq_max][HWOCR_SELECT_WS_INTS] of hwocr_argmax_advance, zero-initialised (or NULL) */
   void *logits;                           /* bf16 [nseq][vocab] */
   void* q8;                               /* E4M3 staging of one prefill GEMM input, rows * max(hidden, Hq*head_dim, inter) bytes, or NULL */
   float* q8s;                             /* its row scales [rows] */

@@ -56,6 +56,9 @@ def _covered():
         gemm |= {_gemm_variant(B, 3584, 1536, 4, 1), _gemm_variant(B, 3584, 1536, 7, 1)}
     attn = {_attn_variant(ns, hd, tiled) for (_, _, _, hd, tiled, _, ns) in ops.ATTN_DECODE_BENCH_CASES}
     attn |= {_attn_variant(ns, hd, tiled) for ns in (1, 4) for hd, tiled in ((128, 0), (128, 1), (256, 0))}
+    # every split case runs twice: partials merged by a second launch, and by the workgroup that arrives last (arrival counters:
+    # test_ops_gpu._same_with_the_last_workgroup_merging) - the form hwocr_decode_step uses
+    attn |= {v[: -len("+merge")] + "+lastwg" for v in attn if v.endswith("+merge")}
     return gemm, attn
 
 

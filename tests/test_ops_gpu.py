@@ -490,6 +490,23 @@ def test_attn_varlen_windows(hd, heads):
     assert (out[offs[-1] + lens[-1]:] == 0).all(), "rows outside every window must stay untouched"
 
 
+def _same_with_the_last_workgroup_merging(out, ptrs, tail, part_o, part_ml):
+    """The split form again with arrival counters (hwocr.h: the workgroup of a (read, kv head) that arrives last merges the partials,
+    no merge launch): the bytes of the two-launch form, twice in a row (the counters go back to zero), counters zero afterwards."""
+    B, Hq, Hkv, nsplit = tail[:4]
+    if nsplit == 1:
+        return
+    arrive = torch.zeros(B * Hkv, dtype=torch.int32, device=DEV)
+    for _ in range(2):
+        part_o.fill_(float("nan"))
+        part_ml.fill_(float("nan"))
+        got = torch.full_like(out, float("nan"))
+        assert lib().hwocr_attn_decode(*ptrs, p(got), p(part_o), p(part_ml), p(arrive), *tail, st()) == 0
+        sync()
+        assert torch.equal(got.view(torch.int16), out.view(torch.int16)), "last-workgroup merge differs from the merge launch"
+        assert int(arrive.abs().sum()) == 0
+
+
 # hd 256: Gemma (MQA: 8 query heads on one kv head), row layout only
 @pytest.mark.parametrize("hd,Hq,Hkv,tiled", [(128, 12, 2, 0), (128, 12, 2, 1), (256, 8, 1, 0)])
 @pytest.mark.parametrize("nsplit", [1, 4])
@@ -510,10 +527,12 @@ def test_attn_decode(nsplit, hd, Hq, Hkv, tiled):
     part_ml = torch.zeros(B * Hkv * nsplit * G * 2, dtype=torch.float32, device=DEV)
     lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
     kk, vv = (tile_k(k), tile_v(vt)) if tiled else (k, vt)
-    rc = lib().hwocr_attn_decode(p(q), p(kk), p(vv), p(lens_d), p(out), p(part_o), p(part_ml), B, Hq, Hkv, nsplit,
+    rc = lib().hwocr_attn_decode(p(q), p(kk), p(vv), p(lens_d), p(out), p(part_o), p(part_ml), None, B, Hq, Hkv, nsplit,
                                  Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, hd, tiled, st())
     assert rc == 0
     sync()
+    _same_with_the_last_workgroup_merging(out, (p(q), p(kk), p(vv), p(lens_d)), (B, Hq, Hkv, nsplit, Hkv * ctx * hd, ctx * hd,
+                                          Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, hd, tiled), part_o, part_ml)
     for b, n in enumerate(lens):
         qq = q[b].float().unsqueeze(1)  # [Hq,1,d]
         want = _sdpa_ref(qq, k[b, :, :n].float(), v[b, :, :n].float(), False, hd ** -0.5).reshape(Hq * hd)
@@ -546,10 +565,12 @@ def test_attn_decode_bench_shapes(B, Hq, Hkv, hd, tiled, ctx, nsplit):
     part_ml = torch.zeros(B * Hkv * nsplit * G * 2, dtype=torch.float32, device=DEV)
     lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
     kk, vv = (tile_k(k), tile_v(vt)) if tiled else (k, vt)
-    rc = lib().hwocr_attn_decode(p(q), p(kk), p(vv), p(lens_d), p(out), p(part_o), p(part_ml), B, Hq, Hkv, nsplit,
+    rc = lib().hwocr_attn_decode(p(q), p(kk), p(vv), p(lens_d), p(out), p(part_o), p(part_ml), None, B, Hq, Hkv, nsplit,
                                  Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, hd, tiled, st())
     assert rc == 0
     sync()
+    _same_with_the_last_workgroup_merging(out, (p(q), p(kk), p(vv), p(lens_d)), (B, Hq, Hkv, nsplit, Hkv * ctx * hd, ctx * hd,
+                                          Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, hd, tiled), part_o, part_ml)
     # fp32 reference of all reads at once: scores masked past each read's length
     kf, vf = k.float().repeat_interleave(G, 1), v.float().repeat_interleave(G, 1)
     s = torch.einsum("bhd,bhkd->bhk", q.float(), kf) * hd ** -0.5
@@ -561,7 +582,7 @@ def test_attn_decode_bench_shapes(B, Hq, Hkv, hd, tiled, ctx, nsplit):
 
 def test_attn_decode_rejects_more_than_16_splits():
     q = randbf(1, 2, 128)
-    assert lib().hwocr_attn_decode(p(q), p(q), p(q), p(q), p(q), p(q), p(q), 1, 2, 1, 17, 128 * 64, 128 * 64, 128 * 64,
+    assert lib().hwocr_attn_decode(p(q), p(q), p(q), p(q), p(q), p(q), p(q), None, 1, 2, 1, 17, 128 * 64, 128 * 64, 128 * 64,
                                    128 * 64, 64, 1.0, 128, 0, st()) == 1
 
 
@@ -979,21 +1000,24 @@ def test_attn_decode_qkv_equals_finish_then_attention(hd, Hq, Hkv, tiled, nsplit
     out0 = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
     assert lib().hwocr_decode_qkv_finish(p(slabs), nslab, B * W, p(bias), p(Q0), p(K0), p(V0), p(lens_d), p(delta_d), p(cos_d),
                                          p(sin_d), B, Hq, Hkv, *strides, hd, tiled, ctx, max_pos, p(st0), st()) == 0
-    assert lib().hwocr_attn_decode(p(Q0), p(K0), p(V0), p(lens_d), p(out0), p(po), p(pm), B, Hq, Hkv, nsplit, *strides,
+    assert lib().hwocr_attn_decode(p(Q0), p(K0), p(V0), p(lens_d), p(out0), p(po), p(pm), None, B, Hq, Hkv, nsplit, *strides,
                                    hd ** -0.5, hd, tiled, st()) == 0
-    # one launch
-    K1, V1 = caches()
-    st1 = torch.zeros(1, dtype=torch.int32, device=DEV)
-    po1, pm1 = parts()
-    out1 = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
-    assert lib().hwocr_attn_decode_qkv(p(slabs), nslab, B * W, p(bias), p(K1), p(V1), p(lens_d), p(delta_d), p(cos_d), p(sin_d),
-                                       p(out1), p(po1), p(pm1), B, Hq, Hkv, nsplit, *strides, hd ** -0.5, hd, tiled, ctx, max_pos,
-                                       p(st1), st()) == 0
-    sync()
-    assert int(st0) == 0 and int(st1) == 0
-    assert torch.equal(K1, K0) and torch.equal(V1, V0), "cache after the fused launch differs"
-    assert torch.equal(out1, out0), "attention output of the fused launch differs"
-    assert bool(torch.isfinite(out1.float()).all())
+    # one launch; with splits, once with the merge launch and once with the last workgroup merging (arrival counters)
+    for lastwg in ([False, True] if nsplit > 1 else [False]):
+        K1, V1 = caches()
+        st1 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        po1, pm1 = parts()
+        arrive = torch.zeros(B * Hkv, dtype=torch.int32, device=DEV) if lastwg else None
+        out1 = torch.zeros(B, Hq * hd, dtype=torch.bfloat16, device=DEV)
+        assert lib().hwocr_attn_decode_qkv(p(slabs), nslab, B * W, p(bias), p(K1), p(V1), p(lens_d), p(delta_d), p(cos_d), p(sin_d),
+                                           p(out1), p(po1), p(pm1), p(arrive), B, Hq, Hkv, nsplit, *strides, hd ** -0.5, hd, tiled,
+                                           ctx, max_pos, p(st1), st()) == 0
+        sync()
+        assert int(st0) == 0 and int(st1) == 0
+        assert torch.equal(K1, K0) and torch.equal(V1, V0), "cache after the fused launch differs"
+        assert torch.equal(out1, out0), "attention output of the fused launch differs"
+        assert bool(torch.isfinite(out1.float()).all())
+        assert arrive is None or int(arrive.abs().sum()) == 0
 
 
 def test_attn_decode_qkv_flags_reads_outside_their_invariants():
@@ -1009,7 +1033,7 @@ def test_attn_decode_qkv_flags_reads_outside_their_invariants():
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
     cos_d, sin_d = cos_t.to(DEV), sin_t.to(DEV)
     assert lib().hwocr_attn_decode_qkv(p(slabs), nslab, B * W, None, p(Kc), p(VT), p(lens), p(delta), p(cos_d), p(sin_d), p(out),
-                                       None, None, B, Hq, Hkv, 1, Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx,
+                                       None, None, None, B, Hq, Hkv, 1, Hkv * ctx * hd, ctx * hd, Hkv * hd * ctx, hd * ctx, ctx,
                                        hd ** -0.5, hd, 0, ctx, max_pos, p(status), st()) == 0
     sync()
     assert int(status) == 1
@@ -1033,43 +1057,54 @@ def test_embed_splice():
     assert torch.equal(out, want)
 
 
-def test_argmax_advance_semantics():
+def _select_ws(split, B):
+    """hwocr_argmax_advance's split_ws (hwocr.h): zero counters -> a row is scanned by 16 workgroups and finished by the last one."""
+    from handwritten_ocr_amd import _lib
+    return torch.zeros(B * _lib.SELECT_WS_INTS, dtype=torch.int32, device=DEV) if split else None
+
+
+# split: the 16-workgroups-per-read form (<= 16 reads and a row of >= 32768 ids), same cases at the model's vocabulary size
+@pytest.mark.parametrize("V,split", [(1000, False), (151936, False), (151936, True)])
+def test_argmax_advance_semantics(V, split):
     import ctypes as C
-    V, B, max_new = 1000, 4, 8
+    B, max_new, E = 4, 8, V - 1
     logits = randbf(B, V, seed=33)
     logits[0, 10] = 50.0
-    logits[0, 20] = 50.0   # tie -> lowest index (torch.argmax picks the first maximum)
-    logits[1, 999] = 60.0  # EOS wins but n_gen < min_new -> suppressed
+    logits[0, V - 20] = 50.0   # tie (in the split form: across workgroups) -> lowest index (torch.argmax picks the first maximum)
+    logits[1, E] = 60.0    # EOS wins but n_gen < min_new -> suppressed
     logits[1, 5] = 55.0
-    logits[2, 999] = 60.0  # EOS, allowed
+    logits[2, E] = 60.0    # EOS, allowed
     logits[3, 7] = 60.0    # already finished -> pad
     cur = torch.zeros(B, dtype=torch.int32, device=DEV)
     lens = torch.tensor([5, 6, 7, 8], dtype=torch.int32, device=DEV)
     n_gen = torch.tensor([0, 0, 3, 3], dtype=torch.int32, device=DEV)
     fin = torch.tensor([0, 0, 0, 1], dtype=torch.int32, device=DEV)
     outt = torch.full((B, max_new), -1, dtype=torch.int32, device=DEV)
-    eos = (C.c_int * 4)(999, 0, 0, 0)
+    eos = (C.c_int * 4)(E, 0, 0, 0)
+    ws = _select_ws(split, B)
     rc = lib().hwocr_argmax_advance(p(logits), V, V, B, p(cur), p(lens), p(n_gen), p(fin), p(outt), max_new, 2, eos, 1,
-                                    123, None, 0, 1.0, st())
+                                    123, None, 0, 1.0, p(ws), st())
     assert rc == 0
     sync()
-    assert cur.tolist() == [10, 5, 999, 123]
+    assert cur.tolist() == [10, 5, E, 123]
     assert lens.tolist() == [6, 7, 8, 9]
     assert n_gen.tolist() == [1, 1, 4, 4]
     assert fin.tolist() == [0, 0, 1, 1]
-    assert outt[0, 0] == 10 and outt[1, 0] == 5 and outt[2, 3] == 999 and outt[3, 3] == 123
+    assert outt[0, 0] == 10 and outt[1, 0] == 5 and outt[2, 3] == E and outt[3, 3] == 123
+    assert ws is None or int(ws.view(B, -1)[:, 0].abs().sum()) == 0   # the arrival counters are zero again
 
 
-def test_argmax_repetition_penalty():
+@pytest.mark.parametrize("V,split", [(1024, False), (151936, False), (151936, True)])
+def test_argmax_repetition_penalty(V, split):
     """HF RepetitionPenaltyLogitsProcessor inside the select kernel: ids in the bitmap have their fp32 score divided
     (positive) or multiplied (negative) by the penalty; the token a step was fed joins the bitmap first (not after a
     prefill, n_gen == 0; not for a finished read)."""
     import ctypes as C
-    V, B, max_new, pen = 1024, 4, 4, 1.5
+    B, max_new, pen, far = 4, 4, 1.5, V - 124
     logits = torch.full((B, V), -3.0, dtype=torch.bfloat16, device=DEV)
     logits[0, 40], logits[0, 41] = 6.0, 5.0      # 40 is in the bitmap: 6 / 1.5 = 4 < 5 -> 41 wins
     logits[1, :] = -8.0
-    logits[1, 7], logits[1, 900] = -2.0, -2.5    # 7 is the token this step was fed: -2 * 1.5 = -3 < -2.5 -> 900 wins
+    logits[1, 7], logits[1, far] = -2.0, -2.5    # 7 is the token this step was fed: -2 * 1.5 = -3 < -2.5 -> `far` wins
     logits[2, 77] = 9.0                          # finished read: pad, bitmap untouched
     logits[3, 12], logits[3, 13] = 6.0, 5.0      # n_gen == 0 (first pick after a prefill): the stale cur_id 12 is NOT added
     seen = torch.zeros(B, V // 32, dtype=torch.int32, device=DEV)
@@ -1079,11 +1114,12 @@ def test_argmax_repetition_penalty():
     n_gen = torch.tensor([2, 1, 1, 0], dtype=torch.int32, device=DEV)
     fin = torch.tensor([0, 0, 1, 0], dtype=torch.int32, device=DEV)
     outt = torch.full((B, max_new), -1, dtype=torch.int32, device=DEV)
-    eos = (C.c_int * 4)(1023, 0, 0, 0)
+    eos = (C.c_int * 4)(V - 1, 0, 0, 0)
+    ws = _select_ws(split, B)
     assert lib().hwocr_argmax_advance(p(logits), V, V, B, p(cur), p(lens), p(n_gen), p(fin), p(outt), max_new, 0, eos, 1, 5,
-                                      p(seen), V // 32, pen, st()) == 0
+                                      p(seen), V // 32, pen, p(ws), st()) == 0
     sync()
-    assert cur.tolist() == [41, 900, 5, 12]
+    assert cur.tolist() == [41, far, 5, 12]
     s = seen.cpu()
     assert int(s[0, 0]) == 1 << 3 and int(s[0, 1]) == 1 << 8      # fed token 3 added; the new pick 41 is not (yet)
     assert int(s[1, 0]) == 1 << 7 and int(s[1].abs().sum()) == 1 << 7
@@ -1091,9 +1127,47 @@ def test_argmax_repetition_penalty():
     # penalty 1: nothing is rescaled
     cur.copy_(torch.tensor([3, 7, 77, 12], dtype=torch.int32))
     assert lib().hwocr_argmax_advance(p(logits), V, V, B, p(cur), p(lens), p(n_gen), p(fin), p(outt), max_new, 0, eos, 1, 5,
-                                      p(seen), V // 32, 1.0, st()) == 0
+                                      p(seen), V // 32, 1.0, p(ws), st()) == 0
     sync()
     assert cur.tolist()[:2] == [40, 7]
+    assert ws is None or int(ws.view(B, -1)[:, 0].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("B", [1, 3, 16])
+def test_argmax_split_form_picks_what_the_one_workgroup_form_picks(B):
+    """Random rows at the model's vocabulary size with planted ties, a penalty bitmap, EOS suppression: 16 workgroups per read + the
+    last one finishing (split_ws) against one workgroup per read, over three consecutive steps (the fed token joins the bitmap)."""
+    import ctypes as C
+    V, max_new = 151936, 4
+    g = torch.Generator().manual_seed(7 + B)
+    eos = (C.c_int * 4)(V - 1, 17, 0, 0)
+
+    def run(split):
+        seen = torch.zeros(B, V // 32, dtype=torch.int32, device=DEV)
+        seen[:, ::7] = 0x10101
+        cur = torch.zeros(B, dtype=torch.int32, device=DEV)
+        lens = torch.full((B,), 9, dtype=torch.int32, device=DEV)
+        n_gen = torch.zeros(B, dtype=torch.int32, device=DEV)
+        fin = torch.zeros(B, dtype=torch.int32, device=DEV)
+        outt = torch.full((B, max_new), -1, dtype=torch.int32, device=DEV)
+        ws = _select_ws(split, B)
+        gg = torch.Generator().manual_seed(11 + B)
+        for step in range(3):
+            logits = (torch.randn(B, V, generator=gg) * 3).to(torch.bfloat16)
+            top = logits.float().max(dim=1).values
+            for b in range(B):  # the maximum again far away (a tie across workgroups) and on an EOS id (suppressed while n_gen < 2)
+                logits[b, (b * 9973 + 140000) % V] = top[b]
+                logits[b, 17] = top[b] + 1
+            logits = logits.to(DEV)
+            assert lib().hwocr_argmax_advance(p(logits), V, V, B, p(cur), p(lens), p(n_gen), p(fin), p(outt), max_new, 2, eos, 2, 0,
+                                              p(seen), V // 32, 1.3, p(ws), st()) == 0
+            sync()
+        return cur.cpu(), outt.cpu(), fin.cpu(), seen.cpu(), n_gen.cpu()
+
+    want, got = run(False), run(True)
+    for w, g_ in zip(want, got):
+        assert torch.equal(w, g_)
+    assert int(want[2].sum()) == B   # step 3 (n_gen == 2 == min_new) picks the EOS id 17: every read finished
 
 
 # ---------------------------------------------------------------------------------------------- fp8 (E4M3) wide GEMM

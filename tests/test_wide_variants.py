@@ -143,7 +143,9 @@ def covered() -> set:
                                                               None))
     lines += _plan(lambda lib: lib.hwocr_embed_splice(ONE, ONE, ONE, ONE, ONE, 64, 256, 1.0, None))           # test_embed_splice
     eos = (C.c_int * 4)(1, 0, 0, 0)
-    lines += _plan(lambda lib: lib.hwocr_argmax_advance(ONE, 512, 512, 4, ONE, ONE, ONE, ONE, ONE, 8, 0, eos, 1, 0, None, 0, 1.0, None))
+    lines += _plan(lambda lib: lib.hwocr_argmax_advance(ONE, 512, 512, 4, ONE, ONE, ONE, ONE, ONE, 8, 0, eos, 1, 0, None, 0, 1.0, None, None))
+    # test_argmax_* at V = 151936 with split_ws: 16 workgroups per read, the last one finishing
+    lines += _plan(lambda lib: lib.hwocr_argmax_advance(ONE, 151936, 151936, 4, ONE, ONE, ONE, ONE, ONE, 8, 0, eos, 1, 0, None, 0, 1.0, ONE, None))
     out = {klass(l) for l in lines}
     # the LM head of a prefill chunk is a decode GEMM at <= 16 rows: those instances are the business of tests/test_decode_variants.py
     gemm, _ = dv._covered()

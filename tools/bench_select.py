@@ -35,7 +35,7 @@ def timeit(fn, reps=20):
 
 
 def greedy():
-    assert lib.hwocr_argmax_advance(p(logits), V, V, R, p(cur), p(lens), p(ng), p(fin), p(out), 8, 0, eos, 0, 0, None, 1, 1.0, st) == 0
+    assert lib.hwocr_argmax_advance(p(logits), V, V, R, p(cur), p(lens), p(ng), p(fin), p(out), 8, 0, eos, 0, 0, None, 1, 1.0, None, st) == 0
 
 
 print(f"{R} reads x vocab {V}: argmax {timeit(greedy):7.1f} us")
