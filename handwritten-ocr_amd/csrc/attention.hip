@@ -737,6 +737,7 @@ struct DecodeArgs {
   // nsplit > 1: one arrival counter per (read, kv head), zero between launches.  The workgroup that arrives last merges the
   // partials itself (nullptr: attn_decode_merge_kernel does, in a launch of its own)
   int* arrive = nullptr;
+  int ahead = 1;  // fused QKV finish: first key block requested before the finish (HWOCR_ATTN_DECODE_AHEAD=0: after, for A/B runs)
 };
 
 // partials of query head h of read b, output feature d: all <= 16 (m, l) pairs and output values are loaded up front (indices
@@ -800,6 +801,40 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
   const int len = a.lens[b];
   const bf16* Kp = a.K + b * a.k_seq + hk * a.k_head;
   const bf16* Vp = a.VT + b * a.v_seq + hk * a.v_head;
+
+  const int krow = 8 * (c >> 2) + (c & 3);  // key (within the block) of tile-0 row c; tile 1: +4
+  const int nblk = (len + 31) >> 5;
+  bf16x8 kf[2][KS], vt[VD];
+  auto load_block = [&](int kb) {
+    const int k0 = kb * 32;
+    if constexpr (TILED) {  // one contiguous KiB per fragment, the cache is stored in operand order
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          kf[t][s] = __builtin_nontemporal_load((const bf16x8*)(Kp + ((((long)kb * 2 + t) * 4 + s) * 64 + lane) * 8));
+#pragma unroll
+      for (int d = 0; d < VD; ++d)
+        vt[d] = __builtin_nontemporal_load((const bf16x8*)(Vp + (((long)kb * 8 + d) * 64 + lane) * 8));
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16* kr = Kp + (long)min(k0 + krow + 4 * t, len - 1) * DEC_HD + 8 * qd;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kf[t][s] = *(const bf16x8*)(kr + 32 * s);
+      }
+#pragma unroll
+      for (int d = 0; d < VD; ++d) vt[d] = *(const bf16x8*)(Vp + (long)(16 * d + c) * a.v_row + k0 + 8 * qd);
+    }
+  };
+  // This wave's first key block is requested BEFORE the q / k / v finish below (3-4 us of slab sums, rotary and a cache append during
+  // which nothing streamed) - unless it is the block that holds the slot being appended (the last one), which has to be read back after.
+  int kb = split * WAVES + w;
+  bool ahead = false;  // wave-uniform
+  if (a.slabs && a.ahead && kb < nblk - 1) {
+    load_block(kb);
+    ahead = true;
+  }
 
   bf16x8 qf[KS];
   if (a.slabs) {
@@ -882,30 +917,10 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
   for (int d = 0; d < VD; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = NEG_BIG, l = 0.f;
 
-  const int krow = 8 * (c >> 2) + (c & 3);  // key (within the block) of tile-0 row c; tile 1: +4
-  const int nblk = (len + 31) >> 5;
-  for (int kb = split * WAVES + w; kb < nblk; kb += a.nsplit * WAVES) {
+  for (; kb < nblk; kb += a.nsplit * WAVES) {
     const int k0 = kb * 32;
-    bf16x8 kf[2][KS], vt[VD];
-    if constexpr (TILED) {  // one contiguous KiB per fragment, the cache is stored in operand order
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-          kf[t][s] = __builtin_nontemporal_load((const bf16x8*)(Kp + ((((long)kb * 2 + t) * 4 + s) * 64 + lane) * 8));
-#pragma unroll
-      for (int d = 0; d < VD; ++d)
-        vt[d] = __builtin_nontemporal_load((const bf16x8*)(Vp + (((long)kb * 8 + d) * 64 + lane) * 8));
-    } else {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const bf16* kr = Kp + (long)min(k0 + krow + 4 * t, len - 1) * DEC_HD + 8 * qd;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) kf[t][s] = *(const bf16x8*)(kr + 32 * s);
-      }
-#pragma unroll
-      for (int d = 0; d < VD; ++d) vt[d] = *(const bf16x8*)(Vp + (long)(16 * d + c) * a.v_row + k0 + 8 * qd);
-    }
+    if (!ahead) load_block(kb);
+    ahead = false;
     if (k0 + 32 > len) {  // tail block: keys past the end carry p = 0, keep 0 * x finite
 #pragma unroll
       for (int d = 0; d < VD; ++d)
@@ -1143,6 +1158,8 @@ extern "C" int hwocr_attn_decode_qkv(const float* slabs, int nslab, long slab_st
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = slab_stride; a.bias = (const bf16*)bias; a.rope_delta = rope_delta;
   a.cos_tab = (const bf16*)cos_tab; a.sin_tab = (const bf16*)sin_tab; a.ctx = ctx; a.max_pos = max_pos; a.status = status;
   a.Kw = (bf16*)K; a.VTw = (bf16*)VT; a.arrive = arrive;
+  static const int ahead = [] { const char* e = getenv("HWOCR_ATTN_DECODE_AHEAD"); return e ? atoi(e) : 1; }();
+  a.ahead = ahead;
   return launch_attn_decode(a, nseq, head_dim, stream);
 }
 
