@@ -46,10 +46,31 @@ constexpr int AHEAD = 7;             // units in flight ahead of the consuming p
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-template <bool FP8, int MH, int NH>
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+template <bool FP8, int MH, int NH, bool WIDE32 = false>
 __device__ __forceinline__ void quadrant_mma(f32x4 (&acc)[4][8], const i32x4 (&wf)[2][2][2], const i32x4 (&xf)[4][2]) {
   __builtin_amdgcn_s_setprio(1);
-  if constexpr (FP8) {
+  if constexpr (WIDE32) {
+    // diagnostic (HWOCR_GEMM_ABLATE=11, WRONG results): the same fragments through HALF as many v_mfma_f32_32x32x16_bf16 - the same
+    // matrix-pipe cycles and LDS traffic, but the pipe holds the SIMD's issue port 8 cycles in 32 instead of 8 in 16
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4(&r)[8] = acc[2 * NH + j];
+        f32x16_t c = __builtin_shufflevector(__builtin_shufflevector(r[4 * MH], r[4 * MH + 1], 0, 1, 2, 3, 4, 5, 6, 7),
+                                             __builtin_shufflevector(r[4 * MH + 2], r[4 * MH + 3], 0, 1, 2, 3, 4, 5, 6, 7), 0, 1, 2, 3, 4, 5,
+                                             6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[NH][j][kk]), __builtin_bit_cast(bf16x8, xf[2 * i + j][kk]), c,
+                                                      0, 0, 0);
+        r[4 * MH] = __builtin_shufflevector(c, c, 0, 1, 2, 3);
+        r[4 * MH + 1] = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+        r[4 * MH + 2] = __builtin_shufflevector(c, c, 8, 9, 10, 11);
+        r[4 * MH + 3] = __builtin_shufflevector(c, c, 12, 13, 14, 15);
+      }
+  } else if constexpr (FP8) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -224,21 +245,21 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
         read_x(st, 0);
         read_w(st, 0, wf[0]);
         issue(K3{}, t + 1);  // unit P + 7
-        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 0, ABL == 11>(acc, wf, xf); else keep_alive(acc, wf, xf);
         phase_end();
         // ph1: (m0, n1)
         read_w(st, 1, wf[1]);
         issue(K0{}, t + 2);
-        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 1, ABL == 11>(acc, wf, xf); else keep_alive(acc, wf, xf);
         phase_end();
         // ph2: (m1, n1)
         read_x(st, 1);
         issue(K1{}, t + 2);
-        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 1, ABL == 11>(acc, wf, xf); else keep_alive(acc, wf, xf);
         phase_end();
         // ph3: (m1, n0); retire K tile t+1, keep the units issued behind it in flight
         issue(K2{}, t + 2);
-        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 0, ABL == 11>(acc, wf, xf); else keep_alive(acc, wf, xf);
         wait_units_in_flight(max(0, min(3, total_units - 1 - (P + 7))));
         phase_end();
       }
@@ -252,22 +273,22 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
         read_w(st, 0, wf[0]);
         issue(K3{}, t + 1);
         phase_end();
-        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 0, ABL == 11>(acc, wf, xf); else keep_alive(acc, wf, xf);
         phase_end();
         read_w(st, 1, wf[1]);
         issue(K0{}, t + 2);
         phase_end();
-        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 0, 1, ABL == 11>(acc, wf, xf); else keep_alive(acc, wf, xf);
         phase_end();
         read_x(st, 1);
         issue(K1{}, t + 2);
         phase_end();
-        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 1>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 1, ABL == 11>(acc, wf, xf); else keep_alive(acc, wf, xf);
         phase_end();
         issue(K2{}, t + 2);
         if (late) wait_units_in_flight(keep);
         phase_end();
-        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 0>(acc, wf, xf); else keep_alive(acc, wf, xf);
+        if constexpr (ABL != 2) quadrant_mma<FP8, 1, 0, ABL == 11>(acc, wf, xf); else keep_alive(acc, wf, xf);
         if (!late) wait_units_in_flight(keep);
         phase_end();
       }
@@ -572,6 +593,12 @@ void launch(const WideArgs& a, hipStream_t st) {
       auto k = ablate == 7 ? gemm_wide256_kernel<EPI_LINEAR, true, false, 7>
                : ablate == 8 ? gemm_wide256_kernel<EPI_LINEAR, true, false, 8>
                              : gemm_wide256_kernel<EPI_LINEAR, true, false, 9>;
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      hipLaunchKernelGGL(k, dim3(persistent_grid(b)), dim3(512), LDS_BYTES, st, b);
+      return;
+    }
+    if (ablate == 11) {
+      auto k = gemm_wide256_kernel<EPI_LINEAR, true, false, 11>;
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       hipLaunchKernelGGL(k, dim3(persistent_grid(b)), dim3(512), LDS_BYTES, st, b);
       return;

@@ -1,7 +1,7 @@
 """Where the 256x256 GEMM's time goes: the product kernel against two ablations of itself (HWOCR_GEMM_ABLATE=1: no LDS-DMA after
 the prologue — matrix pipe + LDS reads + barriers only; =2: no MFMA — staging + LDS reads + barriers only; =3: 1 without barriers;
 =4: 1 without fragment reads; =5: the whole main loop, no epilogue; =6: everything but the epilogue's global stores; =7 / 8 / 9: the epilogue's stores
-non-temporal / sc1 / sc0 sc1 instead of the default policy).  Run on the GPU box once per setting:
+non-temporal / sc1 / sc0 sc1 instead of the default policy; =11: the same fragments through half as many 32x32x16 MFMAs, WRONG results).  Run on the GPU box once per setting:
 HWOCR_GEMM_ABLATE=<0..9> python tools/bench_gemm_ablate.py"""
 import os
 import sys
