@@ -412,7 +412,11 @@ def main() -> None:
     lib = _lib.hip()
     pre_ms = []
 
-    deferred = []  # world > 1 with lanes: (step, token streams) whose gather + merge the MAIN thread does after the lanes are done
+    # world > 1 with lanes: a lane's host thread issues no collective (RCCL wants every rank to issue its collectives in ONE order from
+    # ONE thread); the lanes hand each finished step's token streams to this rank's gather thread, which gathers + merges them in step
+    # order WHILE the lanes read the next steps (inside the timed region, as with one GPU, where the lane threads merge)
+    import threading
+    deferred, deferred_cv = {}, threading.Condition()
 
     def gather_and_merge(toks, n_pages):
         t = torch.tensor(toks, dtype=torch.int32, device=dev)
@@ -430,9 +434,9 @@ def main() -> None:
         e = e or eng
         toks = e.generate(pages, prompts[: len(pages)], max_new=args.new_tokens, min_new=args.new_tokens, hooks=hooks)
         if hooks is not None and world > 1:
-            # a lane's host thread issues no collective: RCCL wants every rank to issue its collectives in one order, from one
-            # thread; the gathers (and the merges behind them) are done by the main thread, in step order, inside the timed region
-            deferred.append((hooks.k, toks))
+            with deferred_cv:
+                deferred[hooks.k] = toks
+                deferred_cv.notify_all()
             return None
         return gather_and_merge(toks, n_pages)
 
@@ -450,10 +454,32 @@ def main() -> None:
 
     def run_steps(k, src=None):
         """k steps through the lanes (lanes == 1: one after the other on this thread's stream): their phase times in step order."""
-        out = pipe.run([(lambda e, hooks, src=src: step(src, e, hooks)) for _ in range(k)])
-        for _, toks in sorted(deferred, key=lambda d: d[0]):
-            gather_and_merge(toks, args.pages)
-        deferred.clear()
+        jobs = [(lambda e, hooks, src=src: step(src, e, hooks)) for _ in range(k)]
+        if world == 1 or len(pipe.engines) == 1 or k <= 1:
+            return pipe.run(jobs)
+        failed = []
+
+        def gather_in_step_order():
+            torch.cuda.set_device(dev)
+            for j in range(k):
+                with deferred_cv:
+                    deferred_cv.wait_for(lambda: j in deferred or failed)
+                    if j not in deferred:
+                        return  # a lane raised: pipe.run re-raises it below (the other ranks meet the collective's timeout)
+                    toks = deferred.pop(j)
+                gather_and_merge(toks, args.pages)
+
+        th = threading.Thread(target=gather_in_step_order, name="hwocr-gather")
+        th.start()
+        try:
+            out = pipe.run(jobs)
+        except BaseException:
+            with deferred_cv:
+                failed.append(True)
+                deferred_cv.notify_all()
+            raise
+        finally:
+            th.join()
         return out
 
     def barrier():

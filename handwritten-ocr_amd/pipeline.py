@@ -19,7 +19,8 @@ in step; nothing orders them on the device.  `order="alternate"` is the fourth r
 asked to be measured): tower(k) waits for prefill(k-1), decode(k) for decode(k-1), by HIP events (`ReadEngine.generate(hooks=...)`).
 Either way everything after a batch's decode (detokenise, compare / merge on the host) runs in that batch's thread; `hooks.ordered()`
 serialises per-batch side effects in batch order.  Collectives are NOT issued from lane threads (RCCL wants one issuing order on every
-rank): with several ranks the caller gathers the batches' token streams from its main thread after `run()` (bench.py).
+rank): with several ranks the caller gathers the batches' token streams from ONE thread of its own, in batch order, as the lanes
+hand them over (bench.py: run_steps).
 
 Results are those of the serial schedule bit for bit: a lane is an ordinary engine over the same weights (`ReadEngine.lane()`: own
 KV cache / state / workspaces) and batches never share state.
