@@ -7,7 +7,8 @@ thread on its own stream; engine B starts half a step after engine A, so that in
 + prefill and vice versa.  Compared with ONE engine doing the same number of batches back to back (the bench's schedule).
 Reports pages/s both ways, the per-phase wall times inside the overlapped run, and the tokens (must be identical).
 
-    python tools/bench_overlap.py [--pages 84] [--batches 4] [--new-tokens 512] [--cus-decode 0]
+    python tools/bench_overlap.py [--pages 84] [--batches 4] [--new-tokens 512] [--lanes 2] [--offsets 0,0.55]
+(CU-masked streams - a partition of the chip between the two halves - are tools/bench_partition.py)
 """
 import argparse
 import os
