@@ -97,43 +97,60 @@ template <int NC>
 __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nch = a.D >> 3;
-  // grid-stride over rows (HWOCR_LN_GRID workgroups, default 4096)
-  for (int row = blockIdx.x * 4 + w; row < a.rows; row += gridDim.x * 4) {
-  float x[NC][8];
-  float s = 0.f;
+  // weight and bias of this lane's chunks: the same for every row of the loop
+  bf16x8 g[NC], bb[NC];
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
-      const bf16x8 v = *(const bf16x8*)(a.x + (long)row * a.ldx + ch * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { x[i][e] = bf2f(v[e]); s += x[i][e]; }
-    }
+    const int ch = min(lane + 64 * i, nch - 1);
+    g[i] = *(const bf16x8*)(a.w + ch * 8);
+    bb[i] = *(const bf16x8*)(a.b + ch * 8);
   }
-  const float mean = wave_sum(s) / a.D;
-  float ss = 0.f;
+  auto load_row = [&](int row, bf16x8 (&v)[NC]) {
 #pragma unroll
-  for (int i = 0; i < NC; ++i)
-    if (lane + 64 * i < nch)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mean; ss += d * d; }
-  const float rstd = 1.0f / sqrtf(wave_sum(ss) / a.D + a.eps);
-  bf16x8 o[NC];
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int ch = lane + 64 * i;
-    if (ch < nch) {
-      const bf16x8 g = *(const bf16x8*)(a.w + ch * 8);
-      const bf16x8 bb = *(const bf16x8*)(a.b + ch * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[i][e] = f2bf((x[i][e] - mean) * rstd * bf2f(g[e]) + bf2f(bb[e]));
-      if (!a.q8) *(bf16x8*)(a.out + (long)row * a.ldo + ch * 8) = o[i];
+    for (int i = 0; i < NC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) v[i] = *(const bf16x8*)(a.x + (long)row * a.ldx + ch * 8);
     }
-  }
-  if (a.q8) e4m3_emit_row(o, lane, nch, a.q8 + (long)row * a.ldq, a.q8s + row);
+  };
+  // grid-stride over rows (HWOCR_LN_GRID workgroups, default 4096), one wave per row; the NEXT row of the wave is requested before
+  // this one is reduced (a row is one round trip to HBM followed by two wave reductions: with nothing in flight behind it the
+  // wave idles for the whole trip - 69 -> 60 us per 62208 x 1280 launch)
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + w;
+  bf16x8 cur[NC], nxt[NC];
+  if (row < a.rows) load_row(row, cur);
+  for (; row < a.rows; row += stride) {
+    if (row + stride < a.rows) load_row(row + stride, nxt);
+    float x[NC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      if (lane + 64 * i < nch)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[i][e] = bf2f(cur[i][e]); s += x[i][e]; }
+    const float mean = wave_sum(s) / a.D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      if (lane + 64 * i < nch)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / a.D + a.eps);
+    bf16x8 o[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[i][e] = f2bf((x[i][e] - mean) * rstd * bf2f(g[i][e]) + bf2f(bb[i][e]));
+        if (!a.q8) *(bf16x8*)(a.out + (long)row * a.ldo + ch * 8) = o[i];
+      }
+    }
+    if (a.q8) e4m3_emit_row(o, lane, nch, a.q8 + (long)row * a.ldq, a.q8s + row);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) cur[i] = nxt[i];
   }
 }
-
 // ------------------------------------------------------------------------------------------------
 // (split-K combine + bias + residual) + RMSNorm.  Replaces Qwen2VLRMSNorm (HF modeling_qwen2_vl.py:96-110:
 // fp32 x*rsqrt(mean(x^2)+eps) -> cast to bf16 -> weight * that) and the two residual adds of the decoder
