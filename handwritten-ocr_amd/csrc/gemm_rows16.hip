@@ -17,7 +17,8 @@
 //   * the output projection adds the residual in its epilogue (in place: an element is read and written by one lane), so it needs
 //     no slabs; gate/up applies SwiGLU / GeGLU in its epilogue as everywhere else; only the long-K down projection still splits K
 //     over workgroups (to reach every CU) and leaves fp32 slabs, which the NEXT layer's QKV prologue (or the final norm) sums.
-// A decoder layer is 6 launches instead of 8 (qkv, attention split + merge, o, gate/up, down); hwocr_decode_step takes this path
+// A decoder layer is 5 launches instead of 8 (qkv, attention split with the last workgroup merging, o, gate/up, down; 6 when the
+// merge is a launch of its own, HWOCR_DECODE_LASTWG=0); hwocr_decode_step takes this path
 // at <= 16 reads when every weight has its bf16 fragment-tiled copy.
 #include "gemm_common.h"
 

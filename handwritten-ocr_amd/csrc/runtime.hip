@@ -345,7 +345,7 @@ static int decode_select(const hwocr_decoder* m, const hwocr_dec_ws* ws, const h
                               gs->rep_penalty, decode_lastwg() ? ws->select_ws : nullptr, st);
 }
 
-// <= 16 reads in flight and every layer GEMM with its bf16 fragment-tiled copy (no E4M3 decode weights): the 6-launch layer of
+// <= 16 reads in flight and every layer GEMM with its bf16 fragment-tiled copy (no E4M3 decode weights): the 5-launch layer of
 // csrc/gemm_rows16.hip.  HWOCR_DECODE_ROWS16=0: the general path at every read count (A/B runs).
 static bool decode_takes_rows16(const hwocr_decoder* m, int nseq) {
   static const bool on = [] { const char* e = getenv("HWOCR_DECODE_ROWS16"); return !e || atoi(e) != 0; }();
@@ -381,7 +381,7 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   decode_splits(m, nseq, s_qkv, s_o, s_d);
   CHECK(hwocr_embed_splice(gs->cur_ids, nullptr, m->embed, nullptr, ws->h, nseq, Hd, G ? m->embed_scale : 1.0f, st));
   if (decode_takes_rows16(m, nseq)) {
-    // ---- at most 16 reads in flight: 6 launches per layer (csrc/gemm_rows16.hip).  The residual stream alternates between
+    // ---- at most 16 reads in flight: 5 launches per layer (csrc/gemm_rows16.hip; 6 with the split attention's merge launch).  The residual stream alternates between
     // ws->h and ws->hn: a layer's QKV projection reads the previous layer's stream + the down projection's slabs in its norm
     // prologue (every workgroup) and writes the updated stream to the OTHER buffer (one workgroup).
     const int sd16 = rows16_down_split(m);
