@@ -107,8 +107,10 @@ def test_a_cu_masked_stream_runs_where_its_mask_says_and_computes_the_same():
     small, hs = stream(set(range(64)))
     big, hb = stream(set(range(64, ncu)))
     try:
-        assert where(small) == {x: 8 for x in range(8)}
-        assert where(big) == {x: (ncu - 64) // 8 for x in range(8)}
+        # (on the boxes of this round: exactly 8 / 24 CUs of every XCD; which physical CUs a part has fused off may shift a few)
+        ws, wb = where(small), where(big)
+        assert sum(ws.values()) == 64 and sorted(ws) == list(range(8)) and all(4 <= v <= 12 for v in ws.values()), ws
+        assert sum(wb.values()) == ncu - 64 and sorted(wb) == list(range(8)) and all(16 <= v <= 32 for v in wb.values()), wb
         g = torch.Generator(device="cuda").manual_seed(3)
         M, N, K = 4096, 1280, 1280
         X = torch.randn(M, K, device="cuda", generator=g).bfloat16()
