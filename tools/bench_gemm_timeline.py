@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Where a tile of the 256x256 GEMM spends its time: HWOCR_GEMM_ABLATE=10 makes wave 0 of every workgroup stamp the 100 MHz
 clock at the start of each tile's main loop, at its end and after the epilogue (EPI_LINEAR bf16 instance).
-    HWOCR_GEMM_ABLATE=10 python tools/bench_gemm_timeline.py [M N K]"""
+    HWOCR_GEMM_ABLATE=10 python tools/bench_gemm_timeline.py [M N K]
+HWOCR_TL_CUS=<n>: the launch goes into a stream masked to n CUs (hwocr_stream_create_cumask) with the persistent grid sized to it:
+what the shader clock and the time per K tile do when fewer CUs draw power."""
 import ctypes as C
 import os
 import sys
@@ -21,8 +23,15 @@ g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
 w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
 out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+cus = int(os.environ.get("HWOCR_TL_CUS", "256"))
+if cus < 256:
+    words = (C.c_uint * 8)(*[sum(1 << b for b in range(32) if 256 - cus <= 32 * wd + b < 256) for wd in range(8)])
+    h = C.c_void_p()
+    _lib.check(hip.hwocr_stream_create_cumask(words, 8, C.byref(h)))
+    torch.cuda.set_stream(torch.cuda.ExternalStream(h.value))
+    hip.hwocr_set_cu_budget(cus)
 st = _lib.stream_handle()
-for _ in range(3):
+for _ in range(8):
     assert hip.hwocr_gemm_wide(_lib.ptr(x), _lib.ptr(w), None, None, _lib.ptr(out), M, N, K, K, K, N, 0, 0, st) == 0
 torch.cuda.synchronize()
 n = 256 * 64 * 4
@@ -31,25 +40,25 @@ lib.hwocr_debug_gemm_timeline.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 assert lib.hwocr_debug_gemm_timeline(buf, n) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(256, 64, 4).astype(np.float64) * 0.01  # us
 tiles = (M + 255) // 256 * ((N + 255) // 256)
-per = [len(range(b, tiles, 256)) for b in range(256)]
+per = [len(range(b, tiles, cus)) for b in range(cus)]
 loop, epi, gap, first = [], [], [], []
-for b in range(256):
+for b in range(cus):
     for i in range(per[b]):
         loop.append(t[b, i, 1] - t[b, i, 0])
         epi.append(t[b, i, 2] - t[b, i, 1])
         if i + 1 < per[b]:
             gap.append(t[b, i + 1, 0] - t[b, i, 2])
-t0 = min(t[b, 0, 0] for b in range(256))
-t1 = max(t[b, per[b] - 1, 2] for b in range(256) if per[b])
-print(f"M={M} N={N} K={K}: {tiles} tiles, {K // 64} K tiles each; kernel span {t1 - t0:.1f} us")
+t0 = min(t[b, 0, 0] for b in range(cus))
+t1 = max(t[b, per[b] - 1, 2] for b in range(cus) if per[b])
+print(f"M={M} N={N} K={K} on {cus} CUs: {tiles} tiles, {K // 64} K tiles each; kernel span {t1 - t0:.1f} us")
 for name, v in (("main loop", loop), ("epilogue (incl. next prologue issue)", epi), ("inter-tile wait + barrier", gap)):
     v = np.asarray(v)
     print(f"  {name:38s} mean {v.mean():6.2f} us   p10 {np.percentile(v, 10):6.2f}   p90 {np.percentile(v, 90):6.2f}")
-print(f"  first main-loop start spread over workgroups: {max(t[b, 0, 0] for b in range(256)) - t0:.2f} us; "
-      f"last tile end spread: {t1 - min(t[b, per[b] - 1, 2] for b in range(256) if per[b]):.2f} us")
+print(f"  first main-loop start spread over workgroups: {max(t[b, 0, 0] for b in range(cus)) - t0:.2f} us; "
+      f"last tile end spread: {t1 - min(t[b, per[b] - 1, 2] for b in range(cus) if per[b]):.2f} us")
 raw = np.frombuffer(buf, dtype=np.uint64).reshape(256, 64, 4)
 mhz = [(float(raw[b, per[b] - 1, 3]) - float(raw[b, 0, 3])) / ((float(raw[b, per[b] - 1, 0]) - float(raw[b, 0, 0])) * 0.01)
-       for b in range(256) if per[b] > 1]
+       for b in range(cus) if per[b] > 1]
 print(f"  shader clock while the kernel runs (s_memtime ticks per wall-clock us): mean {np.mean(mhz):.0f} MHz")
 ideal = 2.0 * 256 * 256 * K / (2.5e15 / 256) * 1e6
 print(f"  MFMA time of one tile at the 2.5 PF peak: {ideal:.2f} us")
