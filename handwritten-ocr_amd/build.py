@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-HIP_SOURCES = ["gemm.hip", "gemm256.hip", "gemm_stream.hip", "gemm_rows16.hip", "attention.hip", "attention_vit80x.hip", "elementwise.hip", "imagepre.hip",
+HIP_SOURCES = ["gemm.hip", "gemm256.hip", "gemm256w4.hip", "gemm_stream.hip", "gemm_rows16.hip", "attention.hip", "attention_vit80x.hip", "elementwise.hip", "imagepre.hip",
                "runtime.hip"]
 # attention_vit80x.hip: its score MFMAs must write arch VGPRs (the accumulator file is owned by its inline asm, see the file)
 EXTRA_FLAGS = {"attention_vit80x.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
