@@ -576,10 +576,15 @@ void launch_one(const WideArgs& b, hipStream_t st) {
 }
 template <int EPI, bool FP8>
 void launch(const WideArgs& a, hipStream_t st) {
-  static const int variant = [] { const char* e = getenv("HWOCR_GEMM256"); return e ? atoi(e) : 2; }();
+  static const int variant = [] { const char* e = getenv("HWOCR_GEMM256"); return e ? atoi(e) : 3; }();  // 3: per-shape choice (default)
   WideArgs b = a;
   b.tilesM = (a.M + BM - 1) / BM;
   b.tilesN = (a.N + BN - 1) / BN;
+  // the four-wave form (gemm256w4.hip) where it exists - bf16, not the fused vision QKV, at least two K tiles - and is the faster one
+  // (its own rule; HWOCR_GEMM256=4: wherever it exists, =2 / =1: never)
+  if constexpr (!FP8 && EPI != EPI_VIT_QKV) {
+    if (variant >= 3 && hwocr_gemm_wide256_w4(b, EPI, variant == 4, st)) return;
+  }
   if (hwocr_plan_on()) {
     hwocr_plan_note("gemm_wide256_kernel<epi=%d,%s,%s> M=%d N=%d K=%d tiles=%d grid=%d rounds=%d ktiles=%d", EPI,
                     variant == 1 ? "lockstep" : "stagger", FP8 ? "e4m3" : "bf16", a.M, a.N, a.K, b.tilesM * b.tilesN, persistent_grid(b),

@@ -16,7 +16,6 @@
 //                t + 1 has landed), then the 16 reads of tile t + 1's k-step-0 fragments.
 // LDS image, swizzle and DMA lane plan are the product kernel's (rows of 128 B, 16-byte chunk p of row r at p ^ ((r >> 1) & 7)).
 // EPI_LINEAR only, one workgroup per tile, plain 8-byte stores: this unit measures the loop, not the epilogue.
-#ifdef HWOCR_DIAG
 #include "gemm_common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -348,6 +347,318 @@ __device__ __forceinline__ f32x4 acc_read(int idx) {
   return f32x4{f0, f1, f2, f3};
 }
 
+// the first MFMA into an accumulator of an output tile takes C = 0 (no zeroing pass over 256 registers per tile)
+__device__ __forceinline__ void acc_mfma_first(int idx, bf16x8 wfrag, bf16x8 xfrag) {
+  switch (idx) {
+    case 0: asm volatile("v_mfma_f32_16x16x32_bf16 a[0:3], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a0", "a1", "a2", "a3"); break;
+    case 1: asm volatile("v_mfma_f32_16x16x32_bf16 a[4:7], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a4", "a5", "a6", "a7"); break;
+    case 2: asm volatile("v_mfma_f32_16x16x32_bf16 a[8:11], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a8", "a9", "a10", "a11"); break;
+    case 3: asm volatile("v_mfma_f32_16x16x32_bf16 a[12:15], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a12", "a13", "a14", "a15"); break;
+    case 4: asm volatile("v_mfma_f32_16x16x32_bf16 a[16:19], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a16", "a17", "a18", "a19"); break;
+    case 5: asm volatile("v_mfma_f32_16x16x32_bf16 a[20:23], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a20", "a21", "a22", "a23"); break;
+    case 6: asm volatile("v_mfma_f32_16x16x32_bf16 a[24:27], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a24", "a25", "a26", "a27"); break;
+    case 7: asm volatile("v_mfma_f32_16x16x32_bf16 a[28:31], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a28", "a29", "a30", "a31"); break;
+    case 8: asm volatile("v_mfma_f32_16x16x32_bf16 a[32:35], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a32", "a33", "a34", "a35"); break;
+    case 9: asm volatile("v_mfma_f32_16x16x32_bf16 a[36:39], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a36", "a37", "a38", "a39"); break;
+    case 10: asm volatile("v_mfma_f32_16x16x32_bf16 a[40:43], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a40", "a41", "a42", "a43"); break;
+    case 11: asm volatile("v_mfma_f32_16x16x32_bf16 a[44:47], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a44", "a45", "a46", "a47"); break;
+    case 12: asm volatile("v_mfma_f32_16x16x32_bf16 a[48:51], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a48", "a49", "a50", "a51"); break;
+    case 13: asm volatile("v_mfma_f32_16x16x32_bf16 a[52:55], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a52", "a53", "a54", "a55"); break;
+    case 14: asm volatile("v_mfma_f32_16x16x32_bf16 a[56:59], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a56", "a57", "a58", "a59"); break;
+    case 15: asm volatile("v_mfma_f32_16x16x32_bf16 a[60:63], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a60", "a61", "a62", "a63"); break;
+    case 16: asm volatile("v_mfma_f32_16x16x32_bf16 a[64:67], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a64", "a65", "a66", "a67"); break;
+    case 17: asm volatile("v_mfma_f32_16x16x32_bf16 a[68:71], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a68", "a69", "a70", "a71"); break;
+    case 18: asm volatile("v_mfma_f32_16x16x32_bf16 a[72:75], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a72", "a73", "a74", "a75"); break;
+    case 19: asm volatile("v_mfma_f32_16x16x32_bf16 a[76:79], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a76", "a77", "a78", "a79"); break;
+    case 20: asm volatile("v_mfma_f32_16x16x32_bf16 a[80:83], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a80", "a81", "a82", "a83"); break;
+    case 21: asm volatile("v_mfma_f32_16x16x32_bf16 a[84:87], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a84", "a85", "a86", "a87"); break;
+    case 22: asm volatile("v_mfma_f32_16x16x32_bf16 a[88:91], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a88", "a89", "a90", "a91"); break;
+    case 23: asm volatile("v_mfma_f32_16x16x32_bf16 a[92:95], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a92", "a93", "a94", "a95"); break;
+    case 24: asm volatile("v_mfma_f32_16x16x32_bf16 a[96:99], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a96", "a97", "a98", "a99"); break;
+    case 25: asm volatile("v_mfma_f32_16x16x32_bf16 a[100:103], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a100", "a101", "a102", "a103"); break;
+    case 26: asm volatile("v_mfma_f32_16x16x32_bf16 a[104:107], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a104", "a105", "a106", "a107"); break;
+    case 27: asm volatile("v_mfma_f32_16x16x32_bf16 a[108:111], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a108", "a109", "a110", "a111"); break;
+    case 28: asm volatile("v_mfma_f32_16x16x32_bf16 a[112:115], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a112", "a113", "a114", "a115"); break;
+    case 29: asm volatile("v_mfma_f32_16x16x32_bf16 a[116:119], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a116", "a117", "a118", "a119"); break;
+    case 30: asm volatile("v_mfma_f32_16x16x32_bf16 a[120:123], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a120", "a121", "a122", "a123"); break;
+    case 31: asm volatile("v_mfma_f32_16x16x32_bf16 a[124:127], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a124", "a125", "a126", "a127"); break;
+    case 32: asm volatile("v_mfma_f32_16x16x32_bf16 a[128:131], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a128", "a129", "a130", "a131"); break;
+    case 33: asm volatile("v_mfma_f32_16x16x32_bf16 a[132:135], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a132", "a133", "a134", "a135"); break;
+    case 34: asm volatile("v_mfma_f32_16x16x32_bf16 a[136:139], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a136", "a137", "a138", "a139"); break;
+    case 35: asm volatile("v_mfma_f32_16x16x32_bf16 a[140:143], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a140", "a141", "a142", "a143"); break;
+    case 36: asm volatile("v_mfma_f32_16x16x32_bf16 a[144:147], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a144", "a145", "a146", "a147"); break;
+    case 37: asm volatile("v_mfma_f32_16x16x32_bf16 a[148:151], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a148", "a149", "a150", "a151"); break;
+    case 38: asm volatile("v_mfma_f32_16x16x32_bf16 a[152:155], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a152", "a153", "a154", "a155"); break;
+    case 39: asm volatile("v_mfma_f32_16x16x32_bf16 a[156:159], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a156", "a157", "a158", "a159"); break;
+    case 40: asm volatile("v_mfma_f32_16x16x32_bf16 a[160:163], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a160", "a161", "a162", "a163"); break;
+    case 41: asm volatile("v_mfma_f32_16x16x32_bf16 a[164:167], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a164", "a165", "a166", "a167"); break;
+    case 42: asm volatile("v_mfma_f32_16x16x32_bf16 a[168:171], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a168", "a169", "a170", "a171"); break;
+    case 43: asm volatile("v_mfma_f32_16x16x32_bf16 a[172:175], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a172", "a173", "a174", "a175"); break;
+    case 44: asm volatile("v_mfma_f32_16x16x32_bf16 a[176:179], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a176", "a177", "a178", "a179"); break;
+    case 45: asm volatile("v_mfma_f32_16x16x32_bf16 a[180:183], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a180", "a181", "a182", "a183"); break;
+    case 46: asm volatile("v_mfma_f32_16x16x32_bf16 a[184:187], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a184", "a185", "a186", "a187"); break;
+    case 47: asm volatile("v_mfma_f32_16x16x32_bf16 a[188:191], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a188", "a189", "a190", "a191"); break;
+    case 48: asm volatile("v_mfma_f32_16x16x32_bf16 a[192:195], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a192", "a193", "a194", "a195"); break;
+    case 49: asm volatile("v_mfma_f32_16x16x32_bf16 a[196:199], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a196", "a197", "a198", "a199"); break;
+    case 50: asm volatile("v_mfma_f32_16x16x32_bf16 a[200:203], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a200", "a201", "a202", "a203"); break;
+    case 51: asm volatile("v_mfma_f32_16x16x32_bf16 a[204:207], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a204", "a205", "a206", "a207"); break;
+    case 52: asm volatile("v_mfma_f32_16x16x32_bf16 a[208:211], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a208", "a209", "a210", "a211"); break;
+    case 53: asm volatile("v_mfma_f32_16x16x32_bf16 a[212:215], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a212", "a213", "a214", "a215"); break;
+    case 54: asm volatile("v_mfma_f32_16x16x32_bf16 a[216:219], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a216", "a217", "a218", "a219"); break;
+    case 55: asm volatile("v_mfma_f32_16x16x32_bf16 a[220:223], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a220", "a221", "a222", "a223"); break;
+    case 56: asm volatile("v_mfma_f32_16x16x32_bf16 a[224:227], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a224", "a225", "a226", "a227"); break;
+    case 57: asm volatile("v_mfma_f32_16x16x32_bf16 a[228:231], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a228", "a229", "a230", "a231"); break;
+    case 58: asm volatile("v_mfma_f32_16x16x32_bf16 a[232:235], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a232", "a233", "a234", "a235"); break;
+    case 59: asm volatile("v_mfma_f32_16x16x32_bf16 a[236:239], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a236", "a237", "a238", "a239"); break;
+    case 60: asm volatile("v_mfma_f32_16x16x32_bf16 a[240:243], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a240", "a241", "a242", "a243"); break;
+    case 61: asm volatile("v_mfma_f32_16x16x32_bf16 a[244:247], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a244", "a245", "a246", "a247"); break;
+    case 62: asm volatile("v_mfma_f32_16x16x32_bf16 a[248:251], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a248", "a249", "a250", "a251"); break;
+    case 63: asm volatile("v_mfma_f32_16x16x32_bf16 a[252:255], %0, %1, 0" ::"v"(wfrag), "v"(xfrag) : "a252", "a253", "a254", "a255"); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The product form of the four-wave loop (HWOCR_GEMM256=4; the eight-wave kernel of gemm256.hip stays the default until this one has
+// been through the bench): persistent tile loop as there - the next tile's 32 prologue DMAs go out before the finished tile's
+// epilogue - with the staged epilogues of gemm256.hip (bias / residual / activations through a 4-KiB-per-wave LDS region, whole
+// 128-byte rows to HBM) walked over the wave's 128 x 128 block as two 64-column halves, and the gated ones (store_glu).
+// bf16 only; the fused vision-QKV epilogue stays with the eight-wave kernel.
+constexpr int W4_LDS = 2 * STAGE + 4 * 4096;
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_wide256w4_kernel(WideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int wr = w >> 1, wc = w & 1;
+  const int ntiles = a.tilesM * a.tilesN;
+  const int nk = a.K >> 6;  // >= 2 (launcher)
+  int tile = blockIdx.x;
+  int m0, n0;
+  auto origin_of = [&](int id) {
+    int tm, tn;
+    tile_of_id(id, a.tilesM, a.tilesN, 4, tm, tn);
+    m0 = tm * BM;
+    n0 = tn * BN;
+  };
+  const int r8 = lane >> 3, p = lane & 7;
+  int voff[16];
+  __amdgpu_buffer_rsrc_t rsrc;
+  auto set_sources = [&]() {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int orow = 128 * (w & 1) + 8 * j + r8;  // waves 0, 1 stage the activation rows, 2, 3 the weight rows
+      const int lc = p ^ ((orow >> 1) & 7);
+      voff[j] = w < 2 ? (min(m0 + orow, a.M - 1) - m0) * a.ldx * 2 + lc * 16 : (min(n0 + orow, a.N - 1) - n0) * a.ldw * 2 + lc * 16;
+    }
+    const char* origin = w < 2 ? (const char*)a.X + (size_t)m0 * a.ldx * 2 : (const char*)a.W + (size_t)n0 * a.ldw * 2;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0x7fffffff, 0x00020000);
+  };
+  const int dst0 = (w < 2 ? 0 : TILE) + (128 * (w & 1)) * 128;
+  auto dma = [&](int t, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(smem + (t & 1) * STAGE + dst0 + j * 1024), 16, voff[j], t * 128, 0, 0);
+  };
+  auto issue_prologue = [&]() {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dma(0, j);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dma(1, j);
+  };
+  const int sw = (c >> 1) & 7;
+  const int xrow0 = (128 * wr + c) * 128;
+  const int wrow0 = TILE + (128 * wc + c) * 128;
+  i32x4 xf[2][8], wf[2][8];
+  auto read_x = [&](const char* st, int kk, int i) { xf[kk][i] = *(const i32x4*)(st + xrow0 + (16 * i) * 128 + (((kk * 4 + q) ^ sw) << 4)); };
+  auto read_w = [&](const char* st, int kk, int j) { wf[kk][j] = *(const i32x4*)(st + wrow0 + (16 * j) * 128 + (((kk * 4 + q) ^ sw) << 4)); };
+
+  origin_of(tile);
+  set_sources();
+  issue_prologue();
+  int after = 0;  // VMEM operations of this wave issued after the prologue DMAs (the epilogue's loads and stores), or -1: unknown
+  while (true) {
+    // K tile 0 of this output tile has landed when only K tile 1's 16 DMAs and whatever was issued after them are outstanding
+    // (vmcnt retires in issue order); edge tiles (stores predicated) wait for everything but the newest 16
+    if (after == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (after == 32) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (after == 56) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    SLOT();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { read_x(smem, 0, i); read_w(smem, 0, i); }
+    SLOT();
+
+    // one K tile: first (k-step 0) and second (k-step 1) half of 64 MFMAs each; DMA: tile t + 2 is requested (not for the last two);
+    // FIRST: the accumulators' first touch
+    auto ktile = [&](int t, auto dma_c, auto first_c) {
+      constexpr bool DMA = decltype(dma_c)::value, FIRST = decltype(first_c)::value;
+      const char* st = smem + (t & 1) * STAGE;
+      const char* sn = smem + ((t + 1) & 1) * STAGE;
+      for_each_slot(std::make_integer_sequence<int, 64>{}, [&](auto ic) {
+        constexpr int s = decltype(ic)::value, j = s >> 3, i = s & 7;
+        if constexpr (FIRST) acc_mfma_first(s, __builtin_bit_cast(bf16x8, wf[0][j]), __builtin_bit_cast(bf16x8, xf[0][i]));
+        else acc_mfma(s, __builtin_bit_cast(bf16x8, wf[0][j]), __builtin_bit_cast(bf16x8, xf[0][i]));
+        SLOT();
+        if (s < 16) {
+          if (s < 8) read_x(st, 1, s);
+          else read_w(st, 1, s - 8);
+          SLOT();
+        }
+        if (s == 24) {
+          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), visible to the compiler's wait bookkeeping
+          __builtin_amdgcn_s_barrier();
+          SLOT();
+        }
+        if (DMA && s >= 26 && ((s - 26) % 6) == 0) {
+          dma(t + 2, (s - 26) / 6);  // DMAs 0..5 of tile t + 2 behind slots 26, 32, ..., 56 (one per six MFMAs: bunched - every third
+          SLOT();                    // or fourth slot - they cost more issue time than the extra slack to land buys, measured)
+        }
+      });
+      for_each_slot(std::make_integer_sequence<int, 64>{}, [&](auto ic) {
+        constexpr int s = decltype(ic)::value, j = s >> 3, i = s & 7;
+        acc_mfma(s, __builtin_bit_cast(bf16x8, wf[1][j]), __builtin_bit_cast(bf16x8, xf[1][i]));
+        SLOT();
+        if (DMA && (s % 6) == 2 && s <= 56) {
+          dma(t + 2, 6 + s / 6);  // DMAs 6..15 behind slots 2, 8, ..., 56
+          SLOT();
+        }
+        if (s == 12) {
+          if constexpr (DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile t + 1 landed: 6 + 2 of tile t + 2 outstanding
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          SLOT();
+        }
+        if (s >= 13 && s < 29) {  // (behind the last K tile these read a stage nobody needs: no branch in the stream)
+          constexpr int f = s - 13;
+          if (f < 8) read_x(sn, 0, f);
+          else read_w(sn, 0, f - 8);
+          SLOT();
+        }
+      });
+    };
+    if (nk > 2) {
+      ktile(0, std::true_type{}, std::true_type{});
+      for (int t = 1; t < nk - 2; ++t) ktile(t, std::true_type{}, std::false_type{});
+      ktile(nk - 2, std::false_type{}, std::false_type{});
+    } else {
+      ktile(0, std::false_type{}, std::true_type{});
+    }
+    ktile(nk - 1, std::false_type{}, std::false_type{});
+
+    // ---- what the epilogue needs from global memory is requested before the next tile's DMAs (gemm256.hip)
+    const int em0 = m0, en0 = n0;
+    bf16x4 bv[8];
+    if constexpr (!is_glu<EPI>) {
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const int n = en0 + 128 * wc + 16 * nt + 4 * q;
+        bv[nt] = (a.bias && n < a.N) ? *(const bf16x4*)(a.bias + n) : bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+      }
+    }
+    // residual rows in the order the 8 store rounds consume them (round = 4 ch + pass: 32 rows x 64 columns), two rounds ahead
+    bf16x8 rs[2][4];
+    auto load_res = [&](int round) {
+      const int ch = round >> 2, pass = round & 3;
+      const int n = en0 + 128 * wc + 64 * ch + 8 * (lane & 7);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = em0 + 128 * wr + 32 * pass + 8 * i + (lane >> 3);
+        rs[round & 1][i] = *(const bf16x8*)(a.res + (size_t)min(m, a.M - 1) * a.ldres + min(n, a.N - 8));
+      }
+    };
+    if constexpr (EPI == EPI_RESIDUAL) {
+      load_res(0);
+      load_res(1);
+    }
+    const bool interior = em0 + BM <= a.M && en0 + BN <= a.N;
+    tile += gridDim.x;
+    const bool more = tile < ntiles;  // workgroup-uniform
+    if (more) {
+      origin_of(tile);
+      set_sources();
+      issue_prologue();
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // the last MFMAs have left the pipe before the accumulators are read
+    if constexpr (is_glu<EPI>) {
+      for_each_slot(std::make_integer_sequence<int, 32>{}, [&](auto ic) {
+        constexpr int k = decltype(ic)::value, mt = k >> 2, np = k & 3;  // gate tile 2 np, up tile 2 np + 1
+        store_glu<EPI>(a, acc_read(8 * (2 * np) + mt), acc_read(8 * (2 * np + 1) + mt), em0 + 128 * wr + 16 * mt + c, en0 + 128 * wc + 32 * np, q);
+      });
+    } else {
+      char* ep = smem + 2 * STAGE + w * 4096;
+      const int pch = lane & 7;
+      for_each_slot(std::make_integer_sequence<int, 8>{}, [&](auto rc) {
+        constexpr int round = decltype(rc)::value, ch = round >> 2, pass = round & 3;
+        const int n = en0 + 128 * wc + 64 * ch + 8 * pch;
+        for_each_slot(std::make_integer_sequence<int, 8>{}, [&](auto tc) {
+          constexpr int k = decltype(tc)::value, mh = k >> 2, nt = k & 3, mt = 2 * pass + mh;
+          const int ml = 16 * mh + c;
+          const f32x4 av = acc_read(8 * (4 * ch + nt) + mt);
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = av[r] + bf2f(bv[4 * ch + nt][r]);
+            if constexpr (EPI == EPI_QUICKGELU) v = act_quick_gelu(rbf(v));
+            else if constexpr (EPI == EPI_GELU) v = act_gelu_erf(rbf(v));
+            else if constexpr (EPI == EPI_GELU_TANH) v = act_gelu_tanh(rbf(v));
+            o[r] = f2bf(v);
+          }
+          *(bf16x4*)(ep + ml * 128 + (((2 * nt + (q >> 1)) ^ (ml & 7)) << 4) + (q & 1) * 8) = o;
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 8 * i + (lane >> 3);
+          v[i] = *(const bf16x8*)(ep + row * 128 + ((pch ^ (row & 7)) << 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 32 * pass + 8 * i + (lane >> 3);
+          const int m = em0 + 128 * wr + row;
+          if (m < a.M && n < a.N) {
+            if constexpr (EPI == EPI_RESIDUAL) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[i][e] = f2bf(bf2f(v[i][e]) + bf2f(rs[round & 1][i][e]));
+            }
+            *(bf16x8*)(a.out + (size_t)m * a.ldo + n) = v[i];
+          }
+        }
+        if constexpr (EPI == EPI_RESIDUAL)
+          if (round < 6) load_res(round + 2);
+      });
+    }
+    if (!more) break;
+    after = !interior ? -1 : (EPI == EPI_RESIDUAL ? 56 : 32);
+  }
+}
+
+// one workgroup per CU the calling thread may count on (hwocr_set_cu_budget), each walking tiles b, b + grid, ...
+inline int w4_grid_cap() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const int budget = hwocr_cu_budget();
+  return budget > 0 && budget < cus ? budget : cus;
+}
+template <int EPI>
+void launch_w4(const WideArgs& b, hipStream_t st) {
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)gemm_wide256w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
+    done = true;
+  }
+  const int ntiles = b.tilesM * b.tilesN, n = w4_grid_cap();
+  hipLaunchKernelGGL((gemm_wide256w4_kernel<EPI>), dim3(ntiles < n ? ntiles : n), dim3(256), W4_LDS, st, b);
+}
+
+#ifdef HWOCR_DIAG
 // ABL (timing variants, WRONG results; bits): 1 = no DMA inside the loop, 2 = no fragment reads inside the loop, 4 = no swizzle on the DMA source
 template <int ABL>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(WideArgs a) {
@@ -435,7 +746,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(WideArgs a) {
         SLOT();
       }
       if (s == 24) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as an instruction the compiler's own wait-count bookkeeping sees (an asm one it does
+        // not: it then re-waits for the same fragments later with counts that also cover newer reads)
         __builtin_amdgcn_s_barrier();
         SLOT();
       }
@@ -460,7 +772,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(WideArgs a) {
         __builtin_amdgcn_s_barrier();
         SLOT();
       }
-      if (s >= 13 && s < 29 && t + 1 < nk) {
+      if (s >= 13 && s < 29) {  // (past the last tile these read a stage nobody needs: no branch in the stream)
         if constexpr (!(ABL & 2)) {
           constexpr int f = s - 13;
           if (f < 8) read_x(sn, 0, f);
@@ -568,7 +880,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4x32_kernel(WideArgs a) {
         SLOT();
       }
       if (s == 19) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as an instruction the compiler's own wait-count bookkeeping sees (an asm one it does
+        // not: it then re-waits for the same fragments later with counts that also cover newer reads)
         __builtin_amdgcn_s_barrier();
         SLOT();
       }
@@ -592,7 +905,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4x32_kernel(WideArgs a) {
         __builtin_amdgcn_s_barrier();
         SLOT();
       }
-      if (s >= 14 && s < 30 && t + 1 < nk) {
+      if (s >= 14 && s < 30) {
         if constexpr (!(ABL & 2)) {
           constexpr int f = s - 14;
           if (f < 8) read_x(sn, 0, f);
@@ -613,7 +926,38 @@ __global__ __launch_bounds__(256, 1) void gemm_w4x32_kernel(WideArgs a) {
   });
 }
 
+#endif  // HWOCR_DIAG (experimental kernels)
+
 }  // namespace
+
+// the four-wave form of hwocr_gemm_wide256 (gemm256.hip: HWOCR_GEMM256=4): bf16, every epilogue but the fused vision QKV; b has
+// tilesM / tilesN filled in.  Returns false when the shape does not qualify (the caller launches the eight-wave kernel).
+bool hwocr_gemm_wide256_w4(const gemm::WideArgs& b, int epi, bool forced, hipStream_t st) {
+  if ((b.K >> 6) < 2 || (b.K & 63)) return false;
+  // Where it is the faster of the two (same-run A/B on the page-read shapes, profiles/r03z_gemm_w4_product.txt): the gated and the plain
+  // epilogues at any K (+3..5 %), bias + residual / activation ones up to K = 2048 (+0..2.5 %); behind a long K loop that streams a big
+  // activation panel (the tower's fc2: 62208 x 1280 x 5120) its shallower prefetch - tile t + 2 can only be requested once tile t has
+  // left its stage - loses 3 %, so those stay with the eight-wave kernel.  HWOCR_GEMM256=4 forces it everywhere, =2 nowhere.
+  if (!forced && !(epi == EPI_LINEAR || epi == EPI_SWIGLU || epi == EPI_GEGLU || b.K <= 2048)) return false;
+  if (hwocr_plan_on()) {
+    const int tiles = b.tilesM * b.tilesN, grid = tiles < w4_grid_cap() ? tiles : w4_grid_cap();
+    hwocr_plan_note("gemm_wide256w4_kernel<epi=%d> M=%d N=%d K=%d tiles=%d grid=%d rounds=%d ktiles=%d", epi, b.M, b.N, b.K, tiles, grid,
+                    (tiles + grid - 1) / grid, b.K >> 6);
+    return true;
+  }
+  switch (epi) {
+    case EPI_LINEAR: launch_w4<EPI_LINEAR>(b, st); return true;
+    case EPI_RESIDUAL: launch_w4<EPI_RESIDUAL>(b, st); return true;
+    case EPI_QUICKGELU: launch_w4<EPI_QUICKGELU>(b, st); return true;
+    case EPI_GELU: launch_w4<EPI_GELU>(b, st); return true;
+    case EPI_GELU_TANH: launch_w4<EPI_GELU_TANH>(b, st); return true;
+    case EPI_SWIGLU: launch_w4<EPI_SWIGLU>(b, st); return true;
+    case EPI_GEGLU: launch_w4<EPI_GEGLU>(b, st); return true;
+  }
+  return false;
+}
+
+#ifdef HWOCR_DIAG
 
 // out[M][N] = bf16(X[M][K] . W[N][K]^T + bias); K % 64 == 0, N % 8 == 0 (diagnostic entry point, not in hwocr.h)
 extern "C" int hwocr_debug_gemm_w4(const void* X, const void* W, const void* bias, void* out, int M, int N, int K, hipStream_t stream) {

@@ -137,4 +137,6 @@ inline bool vit_qkv_fusable(int M, int heads, int hd) {
 int hwocr_gemm_wide256(const gemm::WideArgs& a, int epi, hipStream_t stream);
 int hwocr_gemm_wide256_fp8(const gemm::WideArgs& a, int epi, hipStream_t stream);
 int hwocr_gemm_wide256_vit_qkv(const gemm::WideArgs& a, bool fp8, hipStream_t stream);
+// the four-wave form (gemm256w4.hip); false: shape / epilogue not covered, nothing launched
+bool hwocr_gemm_wide256_w4(const gemm::WideArgs& b, int epi, bool forced, hipStream_t stream);
 

@@ -87,6 +87,19 @@ def test_gemm_wide(M, N, K, epi):
     _check_gemm_wide(M, N, K, epi)
 
 
+# The four-wave form of the 256 x 256 kernel (csrc/gemm256w4.hip; taken for plain / gated epilogues at any K and the others up to
+# K = 2048): its K loop has three forms - 2 K tiles (no steady state, no DMA inside), 3 (first + the two closing tiles), more - and its
+# tile loop two (one tile per workgroup / several, with ragged last panels: the counted wait of the next tile's first K tile then
+# takes the conservative branch).  M >= 1024 so that hwocr_gemm_wide takes the 256 x 256 kernel at all.
+W4_LOOP_CASES = [(1024, 512, 128, 0), (1024, 512, 192, 0), (1100, 520, 256, 0), (1100, 520, 320, 2), (1024, 512, 128, 1), (2048, 768, 192, 1),
+                 (70000, 1032, 128, 1), (70000, 1032, 192, 2), (70000, 1032, 128, 0)]
+
+
+@pytest.mark.parametrize("M,N,K,epi", W4_LOOP_CASES)
+def test_gemm_wide_four_wave_loop_forms(M, N, K, epi):
+    _check_gemm_wide(M, N, K, epi, ulps=2.0 if epi in (0, 1) else 2.5)
+
+
 @pytest.mark.parametrize("M,N,K,epi", WIDE_BENCH_CASES)
 def test_gemm_wide_bench_geometry(M, N, K, epi):
     """Every workgroup of the persistent 256 x 256 kernel walks more than one tile (tiles > 256) — against the fp32 product."""

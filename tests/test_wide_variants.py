@@ -45,6 +45,8 @@ def klass(line: str) -> tuple:
     f = _fields(line)
     if inst.startswith("gemm_wide256_kernel"):
         return (inst, "several tiles per workgroup" if int(f["rounds"]) > 1 else "one tile per workgroup")
+    if inst.startswith("gemm_wide256w4_kernel"):  # + the K loop's forms: 2 K tiles, 3 (no steady-state trip), more
+        return (inst, "several tiles per workgroup" if int(f["rounds"]) > 1 else "one tile per workgroup", "ktiles " + (f["ktiles"] if int(f["ktiles"]) <= 3 else ">3"))
     if inst.startswith("layernorm_kernel"):
         return (inst, "fp8=" + f["fp8"], "several grid trips" if int(f["trips"]) > 1 else "one trip")
     if inst.startswith("add_rmsnorm_kernel"):
@@ -94,7 +96,7 @@ def covered() -> set:
     for M, N, K in ops.WIDE_GEMM_SHAPES:
         for epi in ops.WIDE_GEMM_EPIS:
             lines += _gemm(M, N, K, epi)
-    for M, N, K, epi in ops.WIDE_BENCH_CASES:
+    for M, N, K, epi in ops.WIDE_BENCH_CASES + ops.W4_LOOP_CASES:
         lines += _gemm(M, N, K, epi)
     for M, N, K in ops.WIDE_SWIGLU_SHAPES:
         lines += _gemm(M, N // 32 * 32, K, 4)
@@ -215,7 +217,9 @@ def test_the_plan_sees_the_multi_tile_and_multi_trip_paths_of_the_bench():
 def test_plan_recording_launches_nothing_and_rejects_what_the_launchers_reject():
     lib = _lib.hip()
     assert _plan(lambda l: l.hwocr_gemm_wide(ONE, ONE, None, None, ONE, 2048, 512, 128, 128, 128, 512, 0, 0, None)) == \
-        ["gemm_wide256_kernel<epi=0,stagger,bf16> M=2048 N=512 K=128 tiles=16 grid=16 rounds=1 ktiles=2"]
+        ["gemm_wide256w4_kernel<epi=0> M=2048 N=512 K=128 tiles=16 grid=16 rounds=1 ktiles=2"]   # (plain epilogue: the four-wave form)
+    assert _plan(lambda l: l.hwocr_gemm_wide(ONE, ONE, ONE, ONE, ONE, 2048, 512, 4096, 4096, 4096, 512, 512, 1, None)) == \
+        ["gemm_wide256_kernel<epi=1,stagger,bf16> M=2048 N=512 K=4096 tiles=16 grid=16 rounds=1 ktiles=64"]  # (residual behind a long K loop)
     assert lib.hwocr_plan_begin() == 0
     assert lib.hwocr_gemm_wide(ONE, ONE, None, None, ONE, 64, 64, 72, 72, 72, 64, 0, 0, None) == 1   # K % 64: still refused
     need = C.c_int()
@@ -246,3 +250,16 @@ def test_cu_budget_sizes_the_persistent_grid():
     assert lib.hwocr_stream_create_cumask((C.c_uint * 8)(), 0, C.byref(out)) == 1
     assert lib.hwocr_stream_destroy(None) == 1
     assert lib.hwocr_probe_placement(None, 4, 0, None) == 1
+
+
+def test_the_four_wave_gemm_forms_all_have_parity_cases():
+    """Every code path of gemm_wide256w4_kernel, for every epilogue it is taken for by default, is reached by a parity case: K loop of
+    2 / 3 / more K tiles x one / several tiles per workgroup (classes as `klass` draws them)."""
+    have = covered()
+    w4 = {k for k in have if k[0].startswith("gemm_wide256w4_kernel")}
+    for epi in (0, 1, 2, 4):
+        inst = f"gemm_wide256w4_kernel<epi={epi}>"
+        assert any(k[0] == inst for k in w4), inst
+    for kt in ("ktiles 2", "ktiles 3", "ktiles >3"):
+        for rounds in ("one tile per workgroup", "several tiles per workgroup"):
+            assert any(k[1] == rounds and k[2] == kt for k in w4), (kt, rounds)
