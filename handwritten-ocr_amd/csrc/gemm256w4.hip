@@ -1,8 +1,10 @@
-// EXPERIMENT (diagnostic build only, -DHWOCR_DIAG; tools/bench_gemm_w4.py): the 256x256x64 bf16 GEMM as FOUR waves of 128 x 128 per
-// workgroup - one wave per SIMD with the whole 512-register file - instead of the product kernel's eight waves of 128 x 64.
+// The 256x256x64 bf16 GEMM as FOUR waves of 128 x 128 per workgroup - one wave per SIMD with the whole 512-register file - beside the
+// eight waves of 128 x 64 of gemm256.hip.  gemm_wide256w4_kernel<EPI> is the product kernel (persistent tiles, the epilogues of
+// gemm256.hip; hwocr_gemm_wide256_w4 says for which shapes it is taken); the kernels under HWOCR_DIAG at the end are the experiment it
+// grew out of (tools/bench_gemm_w4.py: timing ablations, the 32x32x16 form, in-kernel cycle stamps).
 //
-// Why again (a first four-wave form lost to the eight-wave kernel in round 1): the product kernel's main loop is
-// 2566 shader cycles per K tile against 2048 of matrix-pipe time at every CU count, under a clock the power budget sets
+// Why (a first four-wave form lost to the eight-wave kernel in round 1): the eight-wave main loop is 2566 shader
+// cycles per K tile against 2048 of matrix-pipe time at every CU count, under a clock the power budget sets
 // (profiles/r03z_gemm_cus.txt), and both the cycles and the power point at the LDS: a wave of 128 x 64 reads (128 + 64) fragment rows
 // per 8192 outputs, a wave of 128 x 128 reads (128 + 128) per 16384 - a third fewer LDS bytes per FLOP.  The vendor library's kernel
 // for these shapes is exactly that shape (dispatch records: 256 threads, 130 KiB LDS), and its loop is one MFMA per slot with at
@@ -10,12 +12,11 @@
 // (__builtin_amdgcn_sched_barrier(0) after every slot).
 //
 // Per K tile t (64 wide; stage t & 1 of two 64-KiB stages; fragments of its two 32-wide k-steps in two register sets):
-//   first half : 64 MFMAs on the k-step-0 fragments; behind them the 16 reads of the k-step-1 fragments, then a barrier (every wave
-//                has everything of tile t in registers: stage t & 1 is free), then the first 8 DMAs of tile t + 2 into it;
-//   second half: 64 MFMAs on the k-step-1 fragments; behind them the other 8 DMAs of tile t + 2, a counted wait + barrier (tile
-//                t + 1 has landed), then the 16 reads of tile t + 1's k-step-0 fragments.
-// LDS image, swizzle and DMA lane plan are the product kernel's (rows of 128 B, 16-byte chunk p of row r at p ^ ((r >> 1) & 7)).
-// EPI_LINEAR only, one workgroup per tile, plain 8-byte stores: this unit measures the loop, not the epilogue.
+//   first half : 64 MFMAs on the k-step-0 fragments; behind the first 16 the reads of the k-step-1 fragments, then a wait + barrier
+//                (every wave has everything of tile t in registers: stage t & 1 is free), then DMAs of tile t + 2 into it;
+//   second half: 64 MFMAs on the k-step-1 fragments; behind them the rest of tile t + 2's 16 DMAs (one per six slots), a counted wait
+//                + barrier (tile t + 1 has landed), then the 16 reads of tile t + 1's k-step-0 fragments.
+// LDS image, swizzle and DMA lane plan are those of gemm256.hip (rows of 128 B, 16-byte chunk p of row r at p ^ ((r >> 1) & 7)).
 #include "gemm_common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -418,8 +419,8 @@ __device__ __forceinline__ void acc_mfma_first(int idx, bf16x8 wfrag, bf16x8 xfr
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// The product form of the four-wave loop (HWOCR_GEMM256=4; the eight-wave kernel of gemm256.hip stays the default until this one has
-// been through the bench): persistent tile loop as there - the next tile's 32 prologue DMAs go out before the finished tile's
+// The product form of the four-wave loop (taken by hwocr_gemm_wide256_w4's rule below; HWOCR_GEMM256=4: wherever it exists, =2: never):
+// persistent tile loop as in gemm256.hip - the next tile's 32 prologue DMAs go out before the finished tile's
 // epilogue - with the staged epilogues of gemm256.hip (bias / residual / activations through a 4-KiB-per-wave LDS region, whole
 // 128-byte rows to HBM) walked over the wave's 128 x 128 block as two 64-column halves, and the gated ones (store_glu).
 // bf16 only; the fused vision-QKV epilogue stays with the eight-wave kernel.
@@ -930,7 +931,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4x32_kernel(WideArgs a) {
 
 }  // namespace
 
-// the four-wave form of hwocr_gemm_wide256 (gemm256.hip: HWOCR_GEMM256=4): bf16, every epilogue but the fused vision QKV; b has
+// the four-wave form of hwocr_gemm_wide256 (called from gemm256.hip's launcher): bf16, every epilogue but the fused vision QKV; b has
 // tilesM / tilesN filled in.  Returns false when the shape does not qualify (the caller launches the eight-wave kernel).
 bool hwocr_gemm_wide256_w4(const gemm::WideArgs& b, int epi, bool forced, hipStream_t st) {
   if ((b.K >> 6) < 2 || (b.K & 63)) return false;
