@@ -936,10 +936,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4x32_kernel(WideArgs a) {
 bool hwocr_gemm_wide256_w4(const gemm::WideArgs& b, int epi, bool forced, hipStream_t st) {
   if ((b.K >> 6) < 2 || (b.K & 63)) return false;
   // Where it is the faster of the two (same-run A/B on the page-read shapes, profiles/r03z_gemm_w4_product.txt): the gated and the plain
-  // epilogues at any K (+3..5 %), bias + residual / activation ones up to K = 2048 (+0..2.5 %); behind a long K loop that streams a big
-  // activation panel (the tower's fc2: 62208 x 1280 x 5120) its shallower prefetch - tile t + 2 can only be requested once tile t has
-  // left its stage - loses 3 %, so those stay with the eight-wave kernel.  HWOCR_GEMM256=4 forces it everywhere, =2 nowhere.
-  if (!forced && !(epi == EPI_LINEAR || epi == EPI_SWIGLU || epi == EPI_GEGLU || b.K <= 2048)) return false;
+  // epilogues at any K (+3..5 %), bias + residual / activation ones up to K = 2048 (+0..2.5 %) and behind a longer K loop when the
+  // output is at least 1536 wide (the decoders' down projections: +2..4.5 %).  A long K loop over FEW column tiles streams a big
+  // activation panel with little reuse (the tower's fc2, 62208 x 1280 x 5120: 5 column tiles): there this kernel's shallower prefetch -
+  // tile t + 2 can only be requested once tile t has left its stage - loses 3 %, so those stay with the eight-wave kernel.
+  // HWOCR_GEMM256=4 forces it everywhere, =2 nowhere.
+  if (!forced && !(epi == EPI_LINEAR || epi == EPI_SWIGLU || epi == EPI_GEGLU || b.K <= 2048 || b.N >= 1536)) return false;
   if (hwocr_plan_on()) {
     const int tiles = b.tilesM * b.tilesN, grid = tiles < w4_grid_cap() ? tiles : w4_grid_cap();
     hwocr_plan_note("gemm_wide256w4_kernel<epi=%d> M=%d N=%d K=%d tiles=%d grid=%d rounds=%d ktiles=%d", epi, b.M, b.N, b.K, tiles, grid,

@@ -219,7 +219,7 @@ def test_plan_recording_launches_nothing_and_rejects_what_the_launchers_reject()
     assert _plan(lambda l: l.hwocr_gemm_wide(ONE, ONE, None, None, ONE, 2048, 512, 128, 128, 128, 512, 0, 0, None)) == \
         ["gemm_wide256w4_kernel<epi=0> M=2048 N=512 K=128 tiles=16 grid=16 rounds=1 ktiles=2"]   # (plain epilogue: the four-wave form)
     assert _plan(lambda l: l.hwocr_gemm_wide(ONE, ONE, ONE, ONE, ONE, 2048, 512, 4096, 4096, 4096, 512, 512, 1, None)) == \
-        ["gemm_wide256_kernel<epi=1,stagger,bf16> M=2048 N=512 K=4096 tiles=16 grid=16 rounds=1 ktiles=64"]  # (residual behind a long K loop)
+        ["gemm_wide256_kernel<epi=1,stagger,bf16> M=2048 N=512 K=4096 tiles=16 grid=16 rounds=1 ktiles=64"]  # (residual, long K loop, few column tiles)
     assert lib.hwocr_plan_begin() == 0
     assert lib.hwocr_gemm_wide(ONE, ONE, None, None, ONE, 64, 64, 72, 72, 72, 64, 0, 0, None) == 1   # K % 64: still refused
     need = C.c_int()
