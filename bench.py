@@ -634,7 +634,8 @@ def main() -> None:
                    "parallelism": f"replicas x{world}, pages sharded, RCCL gather of token streams"},
         "roofline": {"bound": "mfma",
                      "kernel": ("gemm_wide256_kernel<FP8> (E4M3 256x256x128 MFMA GEMM on v_mfma_f32_16x16x128_f8f6f4, 8 waves, staggered phases)"
-                                if args.fp8 else "gemm_wide256_kernel (bf16 256x256x64 MFMA GEMM, 8 waves, staggered phases)"),
+                                if args.fp8 else "gemm_wide256_kernel / gemm_wide256w4_kernel (bf16 256x256x64 MFMA GEMM: 8 waves of 128x64 with staggered phases, or 4 waves "
+                                     "of 128x128 where that form measures faster - HWOCR_GEMM256; every hwocr_gemm_wide launch is timed)"),
                      "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s",
                      "frac": achieved / mfma_peak, "traffic": traffic, "measured_in": roof_where, "in_timed_region": in_region,
                      "traffic_note": "bytes per launch from profiles/pmc_traffic%s.json (separate rocprofv3 --pmc passes)" % ("_fp8" if args.fp8 else ""),

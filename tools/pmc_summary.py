@@ -17,6 +17,8 @@ import sys
 def key(name: str) -> str:
     if re.search(r"gemm_wide256_kernel<\d+, (true|false), true", name):  # the E4M3 instances (<EPI, STAGGER, FP8, ...>)
         return "gemm_wide256_kernel_fp8"
+    if "gemm_wide256w4_kernel" in name:  # the four-wave form of the same GEMM: one family for the traffic figure bench.py reads
+        return "gemm_wide256_kernel"
     m = re.search(r"(gemm_wide256_kernel|gemm_wide_kernel|gemm_skinny_kernel|attn_vit80_kernel|attn_prefill_kernel|"
                   r"attn_decode_kernel|attn_decode_merge_kernel|\w+_kernel)", name)
     return m.group(1) if m else name[:40]
