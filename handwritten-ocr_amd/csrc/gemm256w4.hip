@@ -424,7 +424,7 @@ __device__ __forceinline__ void acc_mfma_first(int idx, bf16x8 wfrag, bf16x8 xfr
 // epilogue - with the staged epilogues of gemm256.hip (bias / residual / activations through a 4-KiB-per-wave LDS region, whole
 // 128-byte rows to HBM) walked over the wave's 128 x 128 block as two 64-column halves, and the gated ones (store_glu).
 // bf16 only; the fused vision-QKV epilogue stays with the eight-wave kernel.
-constexpr int W4_LDS = 2 * STAGE + 4 * 4096;
+constexpr int W4_LDS = 2 * STAGE + 4 * 8192;  // the whole 160 KiB: two operand stages + 2 x 4 KiB of epilogue staging per wave
 
 template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_wide256w4_kernel(WideArgs a) {
@@ -587,11 +587,14 @@ __global__ __launch_bounds__(256, 1) void gemm_wide256w4_kernel(WideArgs a) {
         store_glu<EPI>(a, acc_read(8 * (2 * np) + mt), acc_read(8 * (2 * np + 1) + mt), em0 + 128 * wr + 16 * mt + c, en0 + 128 * wc + 32 * np, q);
       });
     } else {
-      char* ep = smem + 2 * STAGE + w * 4096;
+      // Eight rounds of 32 rows x 64 columns through a staging region PRIVATE to the wave, double-buffered (2 x 4 KiB): round r + 1 is
+      // converted and written while round r's rows are on their way back from LDS - a lone wave per SIMD has no partner to cover
+      // its LDS round trips (two dependent ones per round in the single-buffer form: 13 us of a 41-us fc1 tile sat outside the K loop)
+      char* ep = smem + 2 * STAGE + w * 8192;
       const int pch = lane & 7;
-      for_each_slot(std::make_integer_sequence<int, 8>{}, [&](auto rc) {
+      auto stage_round = [&](auto rc) {
         constexpr int round = decltype(rc)::value, ch = round >> 2, pass = round & 3;
-        const int n = en0 + 128 * wc + 64 * ch + 8 * pch;
+        char* eb = ep + (round & 1) * 4096;
         for_each_slot(std::make_integer_sequence<int, 8>{}, [&](auto tc) {
           constexpr int k = decltype(tc)::value, mh = k >> 2, nt = k & 3, mt = 2 * pass + mh;
           const int ml = 16 * mh + c;
@@ -605,17 +608,24 @@ __global__ __launch_bounds__(256, 1) void gemm_wide256w4_kernel(WideArgs a) {
             else if constexpr (EPI == EPI_GELU_TANH) v = act_gelu_tanh(rbf(v));
             o[r] = f2bf(v);
           }
-          *(bf16x4*)(ep + ml * 128 + (((2 * nt + (q >> 1)) ^ (ml & 7)) << 4) + (q & 1) * 8) = o;
+          *(bf16x4*)(eb + ml * 128 + (((2 * nt + (q >> 1)) ^ (ml & 7)) << 4) + (q & 1) * 8) = o;
         });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+      };
+      stage_round(std::integral_constant<int, 0>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      for_each_slot(std::make_integer_sequence<int, 8>{}, [&](auto rc) {
+        constexpr int round = decltype(rc)::value, ch = round >> 2, pass = round & 3;
+        const int n = en0 + 128 * wc + 64 * ch + 8 * pch;
+        const char* eb = ep + (round & 1) * 4096;
         bf16x8 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = 8 * i + (lane >> 3);
-          v[i] = *(const bf16x8*)(ep + row * 128 + ((pch ^ (row & 7)) << 4));
+          v[i] = *(const bf16x8*)(eb + row * 128 + ((pch ^ (row & 7)) << 4));
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (round < 7) stage_round(std::integral_constant<int, round + 1>{});  // into the other buffer, under the reads
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this round's rows are back, the next round's are written
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
