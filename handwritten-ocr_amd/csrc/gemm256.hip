@@ -486,15 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide256_kernel(WideArgs a) {
             for (int nt = 0; nt < 4; ++nt) {
               const int mt = 2 * pass + mh;
               const int ml = 16 * mh + c;
-              bf16x4 o;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                float v = acc[nt][mt][r] + bf2f(bv[nt][r]);
-                if constexpr (EPI == EPI_QUICKGELU) v = act_quick_gelu(rbf(v));
-                else if constexpr (EPI == EPI_GELU) v = act_gelu_erf(rbf(v));
-                else if constexpr (EPI == EPI_GELU_TANH) v = act_gelu_tanh(rbf(v));
-                o[r] = f2bf(v);
-              }
+              const bf16x4 o = epi_act4<EPI>(acc[nt][mt], bv[nt]);
               *(bf16x4*)(ep + ml * 128 + (((2 * nt + (q >> 1)) ^ (ml & 7)) << 4) + (q & 1) * 8) = o;
             }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own wave's writes are in LDS before any lane reads them

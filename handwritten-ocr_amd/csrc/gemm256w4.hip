@@ -598,16 +598,7 @@ __global__ __launch_bounds__(256, 1) void gemm_wide256w4_kernel(WideArgs a) {
         for_each_slot(std::make_integer_sequence<int, 8>{}, [&](auto tc) {
           constexpr int k = decltype(tc)::value, mh = k >> 2, nt = k & 3, mt = 2 * pass + mh;
           const int ml = 16 * mh + c;
-          const f32x4 av = acc_read(8 * (4 * ch + nt) + mt);
-          bf16x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = av[r] + bf2f(bv[4 * ch + nt][r]);
-            if constexpr (EPI == EPI_QUICKGELU) v = act_quick_gelu(rbf(v));
-            else if constexpr (EPI == EPI_GELU) v = act_gelu_erf(rbf(v));
-            else if constexpr (EPI == EPI_GELU_TANH) v = act_gelu_tanh(rbf(v));
-            o[r] = f2bf(v);
-          }
+          const bf16x4 o = epi_act4<EPI>(acc_read(8 * (4 * ch + nt) + mt), bv[4 * ch + nt]);
           *(bf16x4*)(eb + ml * 128 + (((2 * nt + (q >> 1)) ^ (ml & 7)) << 4) + (q & 1) * 8) = o;
         });
       };

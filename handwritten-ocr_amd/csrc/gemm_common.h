@@ -42,6 +42,47 @@ template <int EPI> __device__ __forceinline__ float glu_gate(float g) {
   else return act_silu(g);
 }
 
+// ---- the same activations on PAIRS of outputs: v_pk_mul_f32 / v_pk_add_f32 do two fp32 operations per issued instruction (each lane
+// half rounded on its own: the results are those of the scalar helpers above bit for bit; -ffp-contract=off keeps the products and sums
+// apart).  An epilogue is 128-256 outputs per lane of vector work with no MFMA beside it: instructions issued are its time.
+__device__ __forceinline__ f32x2 rbf2(f32x2 v) {
+  const bf16x2 b = __builtin_convertvector(v, bf16x2);  // ONE v_cvt_pk_bf16_f32 (two scalar casts compile to two)
+  const unsigned u = __builtin_bit_cast(unsigned, b);
+  return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x2 fast_sigmoid2(f32x2 t) {
+  const f32x2 m = t * -1.44269504f;  // __expf(-t) = exp2(t * -log2(e)), as the scalar form compiles
+  const f32x2 e = {__builtin_amdgcn_exp2f(m[0]), __builtin_amdgcn_exp2f(m[1])};
+  const f32x2 d = e + 1.0f;
+  return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+__device__ __forceinline__ f32x2 act_quick_gelu2(f32x2 v) {
+  const f32x2 t = rbf2(v * 1.702f);
+  const f32x2 s = rbf2(fast_sigmoid2(t));
+  return v * s;
+}
+__device__ __forceinline__ f32x2 act_silu2(f32x2 v) { return v * fast_sigmoid2(v); }
+__device__ __forceinline__ f32x2 act_gelu_tanh2(f32x2 v) {
+  const f32x2 u = (v + (v * v * v) * 0.044715f) * 0.79788456080286535588f;
+  return v * fast_sigmoid2(u * 2.0f);
+}
+// bf16(act(bf16(acc + bias))) of a lane's four outputs (the staged epilogues of the 256 x 256 kernels)
+template <int EPI>
+__device__ __forceinline__ bf16x4 epi_act4(const f32x4& acc, const bf16x4& bias) {
+  bf16x4 o;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x2 v = f32x2{acc[2 * h], acc[2 * h + 1]} + f32x2{bf2f(bias[2 * h]), bf2f(bias[2 * h + 1])};
+    if constexpr (EPI == EPI_QUICKGELU) v = act_quick_gelu2(rbf2(v));
+    else if constexpr (EPI == EPI_GELU_TANH) v = act_gelu_tanh2(rbf2(v));
+    else if constexpr (EPI == EPI_GELU) v = f32x2{act_gelu_erf(rbf(v[0])), act_gelu_erf(rbf(v[1]))};
+    const bf16x2 ob = __builtin_convertvector(v, bf16x2);
+    o[2 * h] = ob[0];
+    o[2 * h + 1] = ob[1];
+  }
+  return o;
+}
+
 struct WideArgs {
   const bf16* X; const bf16* W; const bf16* bias; const bf16* res; bf16* out;
   int M, N, K, ldx, ldw, ldo, ldres, tilesM, tilesN;
@@ -96,7 +137,15 @@ __device__ __forceinline__ void store_glu(const WideArgs& a, const f32x4& g, con
   }
   bf16x4 o;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = f2bf(rbf(glu_gate<EPI>(rbf(g[r] + gb[r]))) * rbf(u[r] + ub[r]));
+  for (int h = 0; h < 2; ++h) {
+    const f32x2 gg = rbf2(f32x2{g[2 * h], g[2 * h + 1]} + f32x2{gb[2 * h], gb[2 * h + 1]});
+    const f32x2 uu = rbf2(f32x2{u[2 * h], u[2 * h + 1]} + f32x2{ub[2 * h], ub[2 * h + 1]});
+    const f32x2 act = EPI == EPI_GEGLU ? act_gelu_tanh2(gg) : act_silu2(gg);
+    const f32x2 y = rbf2(act) * uu;
+    const bf16x2 ob = __builtin_convertvector(y, bf16x2);
+    o[2 * h] = ob[0];
+    o[2 * h + 1] = ob[1];
+  }
   *(bf16x4*)(a.out + (size_t)m * a.ldo + (n_gate >> 1) + 4 * q) = o;
 }
 
