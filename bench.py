@@ -59,6 +59,31 @@ def synthetic_prompt(cfg, n_img: int) -> np.ndarray:
     return np.asarray(pre + [cfg.vision_start_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_id] + suf, np.int32)
 
 
+def wide_gemm_flops_per_read(cfg, hw: tuple[int, int], T: int) -> float:
+    """ALGORITHMIC FLOPs of the Linears / patch conv that run as wide-GEMM launches for ONE read (SURVEY.md 8d's per-unit figure, the
+    GEMM part of it): the model's own dimensions — patches and prompt tokens as they are, K = 3*tps*patch^2 for the patch conv, the
+    tower MLP at its checkpoint width — not the padded ones the launches carry (rows rounded up to 64, K 1176 -> 1216, 3420 -> 3456)."""
+    P = (hw[0] // cfg.patch_size) * (hw[1] // cfg.patch_size)
+    d = cfg.embed_dim
+    patch_k = 3 * cfg.tps * cfg.patch_size ** 2
+    if cfg.family == "qwen2_vl":
+        mlp = 2 * 2.0 * P * d * cfg.mlp_dim
+    elif cfg.family == "qwen2_5_vl":
+        mlp = 3 * 2.0 * P * d * cfg.vit_inter
+    else:
+        mlp = 2 * 2.0 * P * d * cfg.vit_inter
+    vision = 2.0 * P * patch_k * d + cfg.depth * (2.0 * P * d * 4 * d + mlp)
+    if cfg.family == "paligemma":
+        vision += 2.0 * P * d * cfg.hidden                                   # the projector
+    else:
+        m, md = P // cfg.merge ** 2, d * cfg.merge ** 2
+        vision += 2.0 * m * md * md + 2.0 * m * md * cfg.hidden              # the merger's two Linears
+    hd = cfg.head_dim
+    layer = 2.0 * T * cfg.hidden * (cfg.q_heads + 2 * cfg.kv_heads) * hd + 2.0 * T * cfg.q_heads * hd * cfg.hidden \
+        + 3 * 2.0 * T * cfg.hidden * cfg.inter
+    return vision + cfg.layers * layer
+
+
 def strategies_for(reads_per_page: int) -> list:
     from handwritten_ocr_amd.compat import config
 
@@ -291,6 +316,47 @@ def parity_check(device) -> dict:
                                 "flipped near-tie (reported only); the pinned quantities are the teacher-forced ones"}
         except Exception as e:  # a report, never a reason to lose the measurement
             out[fam] = {"error": f"{type(e).__name__}: {e}"}
+    out["trained_cer"] = trained_cer(device)
+    return out
+
+
+def trained_cer(device) -> dict:
+    """The accuracy bar itself (`north_star`: output CER within 0.5 % of the reference's; metric = cer(), ocr_agent/tools.py:103-118,
+    over the text generate() returns, tools.py:764-769): tests/golden/trained_* hold HF's own free-running transcriptions of 8
+    synthetic pages by a briefly TRAINED tiny checkpoint (decisive greedy choices; tools/make_goldens.py::make_trained).  The engine
+    reads the same pages free-running — 8 reads (the <= 16-read decode chain) and 252 reads (the bench's decode geometry) — and the
+    mean CER of its text against HF's is reported (asserted <= 0.005 by tests/test_trained_gpu.py)."""
+    from PIL import Image
+
+    from handwritten_ocr_amd import engine, synth, text, tokenizer
+    from handwritten_ocr_amd.compat import config
+
+    gold = os.path.join(ROOT, "tests", "golden")
+    out = {"bar": 0.005, "metric": "mean over pages of cer(HF text, engine text)"}
+    for fam, stem in (("qwen2_vl", "trained_qwen2vl"), ("qwen2_5_vl", "trained_qwen25vl")):
+        try:
+            with open(os.path.join(gold, stem + ".json"), encoding="utf-8") as f:
+                meta = json.load(f)
+            ckpt = os.path.join(gold, stem)
+            cfg, sd = engine.load_checkpoint_dir(ckpt, device=str(device))
+            cfg.min_pixels, cfg.max_pixels = config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS
+            eng = engine.ReadEngine(cfg, sd, max_reads=252, ctx=512, device=str(device), vit_batch=12, prefill_batch=16)
+            proc = tokenizer.Processor(cfg, tokenizer.HFTokenizer(cfg, ckpt), template_dir=ckpt)
+            cases = meta["cases"]
+            prep = [proc.prepare(Image.fromarray(synth.tint_page(synth.make_page(c["page_seed"], *c["page_hw"]), c["page_tint"]), "RGB"),
+                                 meta["prompt"]) for c in cases]
+            res = {}
+            for reads in (8, 252):
+                idx = [i % len(cases) for i in range(reads)]
+                streams = eng.generate([prep[i][0] for i in idx], [prep[i][1] for i in idx], max_new=meta["max_new_tokens"])
+                texts = [proc.decode(t, skip_special_tokens=True) for t in streams]
+                res[f"{reads}_reads"] = {"mean_cer": sum(text.cer(cases[i]["hf_text"], t) for i, t in zip(idx, texts)) / reads,
+                                         "token_streams_differing_from_hf": sum(t != cases[i]["hf_tokens"] for i, t in zip(idx, streams))}
+            eng.close()
+            out[fam] = dict(res, pages=len(cases), new_tokens=meta["max_new_tokens"],
+                            decisive_fraction_margin_gt_1=meta["decisive_fraction_margin_gt_1"])
+        except Exception as e:
+            out[fam] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -410,7 +476,6 @@ def main() -> None:
     raws_dev = [torch.from_numpy(r).to(dev) for r in raws]                   # the step's input, resident in HBM
     prompts = [synthetic_prompt(cfg, n_img_tokens)] * n_reads
     lib = _lib.hip()
-    pre_ms = []
 
     # world > 1 with lanes: a lane's host thread issues no collective (RCCL wants every rank to issue its collectives in ONE order from
     # ONE thread); the lanes hand each finished step's token streams to this rank's gather thread, which gathers + merges them in step
@@ -449,24 +514,27 @@ def main() -> None:
         pages = [im for raw in (raws_dev if src is None else src) for im in sps[id(e)].pages(raw, strategies, hw)]
         e1.record()
         read_and_merge(pages, args.pages, e, hooks)
-        pre_ms.append(e0.elapsed_time(e1))
-        return dict(e.timings, preprocess_ms=pre_ms[-1])
+        return dict(e.timings, preprocess_ms=e0.elapsed_time(e1))   # (both events long complete: generate synchronised its stream)
 
     def run_steps(k, src=None):
         """k steps through the lanes (lanes == 1: one after the other on this thread's stream): their phase times in step order."""
         jobs = [(lambda e, hooks, src=src: step(src, e, hooks)) for _ in range(k)]
         if world == 1 or len(pipe.engines) == 1 or k <= 1:
             return pipe.run(jobs)
-        failed = []
+        failed, bad_ranks = [], []
 
         def gather_in_step_order():
             torch.cuda.set_device(dev)
             for j in range(k):
                 with deferred_cv:
                     deferred_cv.wait_for(lambda: j in deferred or failed)
-                    if j not in deferred:
-                        return  # a lane raised: pipe.run re-raises it below (the other ranks meet the collective's timeout)
-                    toks = deferred.pop(j)
+                    toks = deferred.pop(j, None)   # None: a lane of THIS rank raised (pipe.run re-raises it below)
+                # every rank says whether it has step j's streams BEFORE the data collective: a rank whose lane raised still takes part
+                # in this one, and the others stop here instead of waiting in the gather until the backend's timeout
+                bad = shard.failed_ranks(toks is not None, dev)
+                if bad:
+                    bad_ranks.extend(bad)
+                    return
                 gather_and_merge(toks, args.pages)
 
         th = threading.Thread(target=gather_in_step_order, name="hwocr-gather")
@@ -480,6 +548,8 @@ def main() -> None:
             raise
         finally:
             th.join()
+        if bad_ranks:
+            raise RuntimeError(f"rank(s) {sorted(set(bad_ranks))} failed in their reads; rank {rank} stops with them")
         return out
 
     def barrier():
@@ -511,7 +581,8 @@ def main() -> None:
     # ---- legs outside `value` (rank 0, N = 1 only): the same step with the raw pages uploaded inside the clock, with the
     # reference's default host preprocessing, and BASELINE config 2 as literally stated (one page, its 3 reads in flight)
     extras = {}
-    if world == 1 and not args.no_extras:
+    solo = world == 1 and not args.no_extras
+    if solo:
         k_up = max(2, 2 * len(pipe.engines))
         torch.cuda.synchronize()
         t = time.perf_counter()
@@ -521,24 +592,27 @@ def main() -> None:
         extras["with_upload"] = {"value": args.pages / up_s, "unit": "pages/s", "ms_per_step": up_s * 1e3, "steps": k_up,
                                  "note": "the timed schedule with the raw pages starting in host memory (pageable): 3 MB per page over "
                                          "PCIe inside the clock"}
-        if len(pipe.engines) > 1:
-            # one batch at a time on one stream (the schedule of rounds 1-2): what the overlap buys, the phase times of a batch that
-            # has the chip to itself, and the dominant kernel's rate when nothing runs beside it
-            _lib.check(lib.hwocr_profile_enable(2 if args.fp8 else 1))
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            seq = [step() for _ in range(2)]
-            torch.cuda.synchronize()
-            seq_s = (time.perf_counter() - t) / 2
-            ms1, fl1, n1 = C.c_double(), C.c_double(), C.c_long()
-            _lib.check(lib.hwocr_profile_read(C.byref(ms1), C.byref(fl1), C.byref(n1)))
-            lib.hwocr_profile_enable(0)
-            extras["one_batch_at_a_time"] = {
-                "value": args.pages / seq_s, "unit": "pages/s", "ms_per_step": seq_s * 1e3,
-                "phases_ms_per_step": {k[:-3]: float(np.mean([p[k] for p in seq])) for k in ("preprocess_ms", "vision_ms", "prefill_ms", "decode_ms")},
-                "dominant_kernel_alone": {"achieved": fl1.value / (ms1.value * 1e-3) / 1e12 if ms1.value > 0 else 0.0, "unit": "TFLOP/s",
-                                          "avg_launch_ms": ms1.value / max(1, n1.value), "launches": int(n1.value)},
-                "note": "--lanes 1: tower, prefill, decode of one batch back to back on one stream"}
+    if len(pipe.engines) > 1 and not args.no_extras:
+        # one batch at a time on one stream (the schedule of rounds 1-2): what the overlap buys, the phase times of a batch that
+        # has the chip to itself, and the dominant kernel's rate when nothing runs beside it.  Run on EVERY rank at every --gpus N
+        # (the step's token gather is a collective): `roofline` then means the same thing in a BENCH line and in a SCALE line —
+        # the kernel alone on rank 0's chip — instead of silently becoming the two-lane in-region figure for N > 1
+        _lib.check(lib.hwocr_profile_enable(2 if args.fp8 else 1))
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        seq = [step() for _ in range(2)]
+        torch.cuda.synchronize()
+        seq_s = (time.perf_counter() - t) / 2
+        ms1, fl1, n1 = C.c_double(), C.c_double(), C.c_long()
+        _lib.check(lib.hwocr_profile_read(C.byref(ms1), C.byref(fl1), C.byref(n1)))
+        lib.hwocr_profile_enable(0)
+        extras["one_batch_at_a_time"] = {
+            "value": args.pages / seq_s, "unit": "pages/s", "ms_per_step": seq_s * 1e3,
+            "phases_ms_per_step": {k[:-3]: float(np.mean([p[k] for p in seq])) for k in ("preprocess_ms", "vision_ms", "prefill_ms", "decode_ms")},
+            "dominant_kernel_alone": {"achieved": fl1.value / (ms1.value * 1e-3) / 1e12 if ms1.value > 0 else 0.0, "unit": "TFLOP/s",
+                                      "avg_launch_ms": ms1.value / max(1, n1.value), "launches": int(n1.value)},
+            "note": "--lanes 1: tower, prefill, decode of one batch back to back on one stream"}
+    if solo:
         t = time.perf_counter()
         host_pages, host_s = host_strategy_pages(cfg, raws, args.reads, dev)
         same = all(torch.equal(a, b) for a, b in zip(host_pages[: 4 * args.reads],
@@ -590,6 +664,12 @@ def main() -> None:
         roof_steps, roof_wall = prof_steps, t_prof
     mean = lambda k: float(np.mean([p[k] for p in phases]))  # noqa: E731
     T = len(prompts[0])
+    # `achieved` = ALGORITHMIC FLOPs (the model's own dimensions, wide_gemm_flops_per_read) of the sampled steps / the HIP-event time
+    # of their wide-GEMM launches; the launches themselves carry ~1 % more (rows padded to 64, K 1176 -> 1216): issued_over_algorithmic
+    alg_per_step = n_reads * wide_gemm_flops_per_read(cfg, hw, T)
+    issued = (alone_leg["achieved"] * 1e12 * roof_ms * 1e-3) if (len(pipe.engines) > 1 and alone_leg) else fl.value
+    achieved = alg_per_step * roof_steps / (roof_ms * 1e-3) / 1e12 if roof_ms > 0 else 0.0
+    in_region["achieved"] = alg_per_step * prof_steps / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     dec_ms = mean("decode_ms") / max(1, args.new_tokens - 1)
     # the decode roofline is a statement about the decode kernels: taken from a batch that has the chip to itself when one was run
     alone = extras.get("one_batch_at_a_time", {}).get("phases_ms_per_step")
@@ -641,7 +721,9 @@ def main() -> None:
                      "traffic_note": "bytes per launch from profiles/pmc_traffic%s.json (separate rocprofv3 --pmc passes)" % ("_fp8" if args.fp8 else ""),
                      "sampled_steps": roof_steps, "launches": int(roof_n), "launches_per_step": int(roof_n) / roof_steps,
                      "avg_launch_ms": roof_ms / max(1, roof_n),
-                     "algorithmic_flops_per_launch": fl.value / max(1, n.value),
+                     "algorithmic_flops_per_launch": alg_per_step * roof_steps / max(1, roof_n),
+                     "algorithmic_flops_per_read": alg_per_step / n_reads,
+                     "issued_over_algorithmic": issued / (alg_per_step * roof_steps) if roof_n else None,
                      "share_of_step_time": roof_ms / (roof_wall * 1e3)},
         "phases_ms_per_step": {"preprocess": mean("preprocess_ms"), "vision": mean("vision_ms"), "prefill": mean("prefill_ms"),
                                "decode": mean("decode_ms"), "decode_per_token": dec_ms,

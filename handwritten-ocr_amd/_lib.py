@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 SELECT_WS_INTS = 40  # HWOCR_SELECT_WS_INTS
-ABI_VERSION = 12  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
+ABI_VERSION = 13  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
 
 P = C.c_void_p
 I = C.c_int
@@ -151,6 +151,7 @@ _HIP_SIGS = {
     "hwocr_prefill": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), P, P, P, P, P, P,
                        I, I, I, I, P], I),
     "hwocr_decode_step": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), I, I, P], I),
+    "hwocr_decode_slab_floats": ([C.POINTER(Decoder), I], C.c_long),
     "hwocr_decode_graph_create": ([C.POINTER(Decoder), C.POINTER(DecWs), C.POINTER(Kv), C.POINTER(GenState), I, I,
                                    C.POINTER(P)], I),
     "hwocr_decode_graph_launch": ([P, I, P], I),
@@ -195,6 +196,12 @@ def hip() -> C.CDLL:
         # (streams and pointers of one are "no device" to the other).
         import torch  # noqa: F401
 
+        if os.environ.get("HWOCR_DIAG_LIB", "0") not in ("", "0"):
+            # measurement runs only (tools/ab_env.sh): the -DHWOCR_DIAG build, in which the A/B switches of concluded experiments exist
+            import sys
+
+            sys.stderr.write("hwocr: HWOCR_DIAG_LIB set - loading the DIAGNOSTIC library (A/B switches live; not the shipped code)\n")
+            _build.use_diag_library()
         if not os.path.exists(_build.HIP_LIB):
             raise HwocrError(
                 f"{_build.HIP_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`; "

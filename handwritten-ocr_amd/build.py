@@ -49,7 +49,7 @@ def build_hip(force: bool = False, diag: bool = False) -> str:
     loads unless a tool points it there (use_diag_library)."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attention_args.h"),
-                   os.path.join(INCLUDE, "hwocr.h")]
+                   os.path.join(CSRC, "diag_src", "gemm256w4_experiments.inc"), os.path.join(INCLUDE, "hwocr.h")]
     target = DIAG_LIB if diag else HIP_LIB
     if not force and _newer(target, deps):
         return target

@@ -432,20 +432,20 @@ __global__ __launch_bounds__(64 * WAVES, 1) void attn_hd256_kernel(PrefillArgs a
   }
 }
 
-// HWOCR_ATTN_SLACK: log2 slack of the lazy running-max update (default 8: weights up to 256; 0 = exact schedule)
+// log2 slack of the lazy running-max update: 8 = weights up to 256 (0 = exact schedule; HWOCR_ATTN_SLACK in the diagnostic build)
 inline float attn_slack() {
-  static const float v = [] { const char* e = getenv("HWOCR_ATTN_SLACK"); return e ? (float)atof(e) : 8.0f; }();
+  static const float v = HWOCR_DIAG_ENV_FLOAT("HWOCR_ATTN_SLACK", 8.0f);
   return v;
 }
 
 template <int WAVES>
 int launch_hd256(PrefillArgs a, int nseg, int heads, int max_len, hipStream_t st) {
   HWOCR_PLAN("attn_hd256_kernel<%d> nseg=%d heads=%d group=%d max_len=%d", WAVES, nseg, heads, a.group, max_len);
-  static bool done = false;
-  if (!done) {
+  static const bool done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     hipFuncSetAttribute((const void*)attn_hd256_kernel<WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G256_STAGE);
-    done = true;
-  }
+    return true;
+  }();
+  (void)done;
   a.qblocks = (max_len + 32 * WAVES - 1) / (32 * WAVES);
   a.slack = attn_slack();
   hipLaunchKernelGGL((attn_hd256_kernel<WAVES>), dim3(a.qblocks * heads * nseg), dim3(64 * WAVES), 2 * G256_STAGE, st, a);
@@ -458,11 +458,11 @@ int launch_prefill(const PrefillArgs& a, int nseg, int heads, int max_len, hipSt
   constexpr int LDS = 2 * (64 * (HD * 2 + 16) + HDP * 144);
   HWOCR_PLAN("attn_prefill_kernel<%d,%s> nseg=%d heads=%d group=%d max_len=%d tiled=%d varlen=%d", HD, CAUSAL ? "causal" : "full", nseg,
              heads, a.group, max_len, a.kv_tiled, a.seg_off != nullptr);
-  static bool done = false;
-  if (!done) {
+  static const bool done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     hipFuncSetAttribute((const void*)attn_prefill_kernel<HD, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    done = true;
-  }
+    return true;
+  }();
+  (void)done;
   dim3 grid((max_len + 127) / 128, heads, nseg), block(256);
   hipLaunchKernelGGL((attn_prefill_kernel<HD, CAUSAL>), grid, block, LDS, st, a);
   return hwocr_launch_status();
@@ -706,11 +706,11 @@ int launch_vit80(const PrefillArgs& a, int nseg, int heads, int max_len, hipStre
   b.qblocks = (max_len + 32 * waves - 1) / (32 * waves);
   b.slack = attn_slack();
   if (waves == 12) {
-    static bool done = false;
-    if (!done) {
+    static const bool done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
       (void)hipFuncSetAttribute((const void*)attn_vit80_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V80_STAGE);
-      done = true;
-    }
+      return true;
+    }();
+    (void)done;
     hipLaunchKernelGGL(attn_vit80_kernel<12>, dim3(b.qblocks * heads * nseg), dim3(768), 2 * V80_STAGE, st, b);
   } else {
     hipLaunchKernelGGL(attn_vit80_kernel<4>, dim3(b.qblocks * heads * nseg), dim3(256), 2 * V80_STAGE, st, b);
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
   // which nothing streamed) - unless it is the block that holds the slot being appended (the last one), which has to be read back after.
   int kb = split * WAVES + w;
   bool ahead = false;  // wave-uniform
-  if (a.slabs && a.ahead && kb < nblk - 1) {
+  if (a.slabs && a.ahead && kb < nblk - 1 && len <= a.ctx) {  // (len > ctx: a broken host invariant - flagged below, nothing is read)
     load_block(kb);
     ahead = true;
   }
@@ -1053,7 +1053,7 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
                 group, scale * 1.4426950408889634f, kv_tiled, heads, nseg, (max_len + 127) / 128};
   if (kv_tiled && head_dim != 128) return HWOCR_EINVAL;
   if (head_dim == 80 && !causal && group == 1) {
-    static const bool generic = [] { const char* e = getenv("HWOCR_ATTN_GENERIC"); return e && atoi(e) != 0; }();
+    static const bool generic = HWOCR_DIAG_ENV_INT("HWOCR_ATTN_GENERIC", 0) != 0;
     if (!generic) return launch_vit80(a, nseg, heads, max_len, stream);
   }
   if (head_dim == 80) return causal ? launch_prefill<80, true>(a, nseg, heads, max_len, stream)
@@ -1065,7 +1065,7 @@ extern "C" int hwocr_attn_prefill(const void* Q, const void* K, const void* VT, 
     // 256 + VGPRs per wave: hipcc spills 74 of them and the kernel measured no faster than the generic one.  32-key tiles
     // in four LDS stages - three tiles in flight instead of one - measured 4.1-4.3 ms at 4 waves and 3.6-4.2 ms at 8 (21-35
     // spills) against 3.47 ms: the time is not DMA latency.)
-    static const int waves = [] { const char* e = getenv("HWOCR_HD256_WAVES"); return e ? atoi(e) : 4; }();
+    static const int waves = HWOCR_DIAG_ENV_INT("HWOCR_HD256_WAVES", 4);
     if (waves == 4) return launch_hd256<4>(a, nseg, heads, max_len, stream);
   }
   if (head_dim == 256) return causal ? launch_prefill<256, true>(a, nseg, heads, max_len, stream)
@@ -1158,7 +1158,7 @@ extern "C" int hwocr_attn_decode_qkv(const float* slabs, int nslab, long slab_st
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = slab_stride; a.bias = (const bf16*)bias; a.rope_delta = rope_delta;
   a.cos_tab = (const bf16*)cos_tab; a.sin_tab = (const bf16*)sin_tab; a.ctx = ctx; a.max_pos = max_pos; a.status = status;
   a.Kw = (bf16*)K; a.VTw = (bf16*)VT; a.arrive = arrive;
-  static const int ahead = [] { const char* e = getenv("HWOCR_ATTN_DECODE_AHEAD"); return e ? atoi(e) : 1; }();
+  static const int ahead = HWOCR_DIAG_ENV_INT("HWOCR_ATTN_DECODE_AHEAD", 1);
   a.ahead = ahead;
   return launch_attn_decode(a, nseq, head_dim, stream);
 }

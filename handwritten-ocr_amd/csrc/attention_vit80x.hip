@@ -436,11 +436,11 @@ __global__ __launch_bounds__(256, 1) void attn_vit80x_kernel(PrefillArgs a) {
 }  // namespace
 
 void hwocr_attn::launch_vit80x(const PrefillArgs& a, int grid, hipStream_t st) {
-  static bool done = false;
-  if (!done) {
+  static const bool done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     (void)hipFuncSetAttribute((const void*)attn_vit80x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V80X_STAGES * V80_STAGE);
-    done = true;
-  }
+    return true;
+  }();
+  (void)done;
   hipLaunchKernelGGL(attn_vit80x_kernel, dim3(grid), dim3(256), V80X_STAGES * V80_STAGE, st, a);
 }
 

@@ -62,6 +62,20 @@ __device__ __forceinline__ long kv_tiled_v(int d, int key) {
   return ((((long)(key >> 5) * 8 + (d >> 4)) * 64 + (kl >> 3) * 16 + (d & 15)) << 3) + (kl & 7);
 }
 
+// Switches of CONCLUDED A/B experiments (kernel-path choices whose outcome is recorded in DESIGN.md / docs/LAB_NOTEBOOK.md) exist only in
+// the diagnostic build (-DHWOCR_DIAG, csrc/diag/, loaded by tools/ through build.use_diag_library()): there the variable is read
+// once per process; in the product library the expression IS the default, no name is compiled in and no untested path can be
+// selected from the environment.  The one switch the product library keeps is HWOCR_VIT80_KERNEL (attention.hip; read per call and
+// walked by tests/test_ops_gpu.py in one process).
+#ifdef HWOCR_DIAG
+#include <stdlib.h>
+#define HWOCR_DIAG_ENV_INT(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#define HWOCR_DIAG_ENV_FLOAT(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? (float)atof(e_) : (dflt); }())
+#else
+#define HWOCR_DIAG_ENV_INT(name, dflt) (dflt)
+#define HWOCR_DIAG_ENV_FLOAT(name, dflt) (dflt)
+#endif
+
 // last launch failure of this process (which launcher, which HIP error): read back through hwocr_last_error()
 extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text);
 static inline int hwocr_launch_status_at(const char* where) {

@@ -1050,7 +1050,7 @@ static void launch_by_chunks(int D, int grid, hipStream_t st, const Args& a) {
 }
 
 static int ln_grid(int rows) {
-  static const int cap = [] { const char* e = getenv("HWOCR_LN_GRID"); return e ? atoi(e) : 4096; }();  // (62208 x 1280, cold: 75 us uncapped, 70 at 4096, 83 at 2048)
+  static const int cap = HWOCR_DIAG_ENV_INT("HWOCR_LN_GRID", 4096);  // (62208 x 1280, cold: 75 us uncapped, 70 at 4096, 83 at 2048)
   const int need = (rows + 3) / 4;
   return need < cap ? need : cap;
 }

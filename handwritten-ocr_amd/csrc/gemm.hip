@@ -276,12 +276,12 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_skinny_kernel(SkinnyArgs a) {
 template <int NB, int EPI, int NT, int WAVES, int KC, bool TILED>
 void launch_skinny_one(const SkinnyArgs& a, int splitk, hipStream_t st) {
   constexpr int LDS = 2 * NB * 16 * KC * 2;
-  static bool done = false;
-  if (!done) {
+  static const bool done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<NB, EPI, NT, WAVES, KC, TILED>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    done = true;
-  }
+    return true;
+  }();
+  (void)done;
   const int rows = 16 * NT * WAVES;
   dim3 grid((a.N + rows - 1) / rows, splitk), block(64 * WAVES);
   hipLaunchKernelGGL((gemm_skinny_kernel<NB, EPI, NT, WAVES, KC, TILED>), grid, block, LDS, st, a);
@@ -383,7 +383,7 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
              M, N, K, ldx, ldw, ldo, ldres, (M + BM - 1) / BM, (N + BN - 1) / BN};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   const bool prof = g_prof.on == 1 && g_prof.reserve(ev0, ev1, 2.0 * M * (double)N * K);
-  static const bool use256 = [] { const char* e = getenv("HWOCR_GEMM256"); return !e || atoi(e) != 0; }();
+  static const bool use256 = HWOCR_DIAG_ENV_INT("HWOCR_GEMM256", 3) != 0;
   if (use256 && M >= 1024 && N >= 256 && (ldo % 8) == 0 && (epi != EPI_RESIDUAL || (ldres % 8) == 0)) {
     if (prof) (void)hipEventRecord(ev0, stream);
     const int rc = hwocr_gemm_wide256(a, epi, stream);
@@ -394,8 +394,7 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
   }
   HWOCR_PLAN("gemm_wide_kernel<epi=%d> M=%d N=%d K=%d tiles=%d", epi, M, N, K, a.tilesM * a.tilesN);
   dim3 grid(a.tilesM * a.tilesN), block(256);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static const bool attr_done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_LINEAR>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_QUICKGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
@@ -403,8 +402,9 @@ extern "C" int hwocr_gemm_wide(const void* X, const void* W, const void* bias, c
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_GELU_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
     hipFuncSetAttribute((const void*)gemm_wide_kernel<EPI_GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS);
-    attr_done = true;
-  }
+    return true;
+  }();
+  (void)attr_done;
   if (prof) (void)hipEventRecord(ev0, stream);
   switch (epi) {
     case EPI_LINEAR: hipLaunchKernelGGL(gemm_wide_kernel<EPI_LINEAR>, grid, block, WIDE_LDS, stream, a); break;
@@ -500,7 +500,7 @@ bool skinny_args_ok(int Bsz, int N, int K, int ldx, int ldw, int ldo, int epi, i
 }
 bool skinny_takes_stream(int Bsz, int N, int K, int epi, int splitk, int w_tiled) {
   // fragment-tiled weights: the LDS-DMA streaming kernel (gemm_stream.hip)
-  static const bool use_stream = [] { const char* e = getenv("HWOCR_GEMM_STREAM"); return !e || atoi(e) != 0; }();
+  static const bool use_stream = HWOCR_DIAG_ENV_INT("HWOCR_GEMM_STREAM", 1) != 0;
   if (!(use_stream && w_tiled && Bsz <= 256 && (K % 64) == 0)) return false;
   const int ktiles = K / 64, per = (ktiles + splitk - 1) / splitk;
   // a plain linear over more than one round of 16-tile groups (the LM head) re-stages x once per group: the older

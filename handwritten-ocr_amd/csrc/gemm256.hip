@@ -558,17 +558,17 @@ inline int persistent_grid(const WideArgs& b) {
 
 template <int EPI, bool STAGGER, bool FP8>
 void launch_one(const WideArgs& b, hipStream_t st) {
-  static bool done = false;
-  if (!done) {
+  static const bool done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     (void)hipFuncSetAttribute((const void*)gemm_wide256_kernel<EPI, STAGGER, FP8>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    done = true;
-  }
+    return true;
+  }();
+  (void)done;
   hipLaunchKernelGGL((gemm_wide256_kernel<EPI, STAGGER, FP8>), dim3(persistent_grid(b)), dim3(512), LDS_BYTES, st, b);
 }
 template <int EPI, bool FP8>
 void launch(const WideArgs& a, hipStream_t st) {
-  static const int variant = [] { const char* e = getenv("HWOCR_GEMM256"); return e ? atoi(e) : 3; }();  // 3: per-shape choice (default)
+  static const int variant = HWOCR_DIAG_ENV_INT("HWOCR_GEMM256", 3);  // 3: per-shape choice between the two forms (the product's rule)
   WideArgs b = a;
   b.tilesM = (a.M + BM - 1) / BM;
   b.tilesN = (a.N + BN - 1) / BN;
@@ -583,7 +583,7 @@ void launch(const WideArgs& a, hipStream_t st) {
                     (b.tilesM * b.tilesN + persistent_grid(b) - 1) / persistent_grid(b), a.K * (FP8 ? 1 : 2) / 128);
     return;
   }
-#ifdef HWOCR_DIAG  // diagnostic builds only (tools/diag_build.py): kernel variants that give WRONG results by construction
+#ifdef HWOCR_DIAG  // diagnostic builds only (build.use_diag_library(), csrc/diag/): kernel variants that give WRONG results by construction
   if constexpr (EPI == EPI_LINEAR && !FP8) {
     static const int ablate = [] { const char* e = getenv("HWOCR_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     if (ablate >= 7 && ablate <= 9) {  // store policies of the epilogue (results stay correct): 7 nt, 8 sc1, 9 sc0 sc1

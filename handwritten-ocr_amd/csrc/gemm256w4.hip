@@ -35,104 +35,6 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define SLOT() __builtin_amdgcn_sched_barrier(0)
 
-// per workgroup (wave 0): shader cycles and 100 MHz ticks of the main loop of the last launch
-__device__ unsigned long long g_w4_stamps[2 * 8192];
-
-// ---- the same for sixteen 32 x 32 accumulators (tile idx = 4 jb + ib -> a[16 idx : 16 idx + 15]) of v_mfma_f32_32x32x16_bf16
-__device__ __forceinline__ void acc32_mfma(int idx, bf16x8 wfrag, bf16x8 xfrag) {
-  switch (idx) {
-    case 0: asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" ::"v"(wfrag), "v"(xfrag) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"); break;
-    case 1: asm volatile("v_mfma_f32_32x32x16_bf16 a[16:31], %0, %1, a[16:31]" ::"v"(wfrag), "v"(xfrag) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"); break;
-    case 2: asm volatile("v_mfma_f32_32x32x16_bf16 a[32:47], %0, %1, a[32:47]" ::"v"(wfrag), "v"(xfrag) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47"); break;
-    case 3: asm volatile("v_mfma_f32_32x32x16_bf16 a[48:63], %0, %1, a[48:63]" ::"v"(wfrag), "v"(xfrag) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"); break;
-    case 4: asm volatile("v_mfma_f32_32x32x16_bf16 a[64:79], %0, %1, a[64:79]" ::"v"(wfrag), "v"(xfrag) : "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79"); break;
-    case 5: asm volatile("v_mfma_f32_32x32x16_bf16 a[80:95], %0, %1, a[80:95]" ::"v"(wfrag), "v"(xfrag) : "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"); break;
-    case 6: asm volatile("v_mfma_f32_32x32x16_bf16 a[96:111], %0, %1, a[96:111]" ::"v"(wfrag), "v"(xfrag) : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111"); break;
-    case 7: asm volatile("v_mfma_f32_32x32x16_bf16 a[112:127], %0, %1, a[112:127]" ::"v"(wfrag), "v"(xfrag) : "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"); break;
-    case 8: asm volatile("v_mfma_f32_32x32x16_bf16 a[128:143], %0, %1, a[128:143]" ::"v"(wfrag), "v"(xfrag) : "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143"); break;
-    case 9: asm volatile("v_mfma_f32_32x32x16_bf16 a[144:159], %0, %1, a[144:159]" ::"v"(wfrag), "v"(xfrag) : "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159"); break;
-    case 10: asm volatile("v_mfma_f32_32x32x16_bf16 a[160:175], %0, %1, a[160:175]" ::"v"(wfrag), "v"(xfrag) : "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175"); break;
-    case 11: asm volatile("v_mfma_f32_32x32x16_bf16 a[176:191], %0, %1, a[176:191]" ::"v"(wfrag), "v"(xfrag) : "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191"); break;
-    case 12: asm volatile("v_mfma_f32_32x32x16_bf16 a[192:207], %0, %1, a[192:207]" ::"v"(wfrag), "v"(xfrag) : "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207"); break;
-    case 13: asm volatile("v_mfma_f32_32x32x16_bf16 a[208:223], %0, %1, a[208:223]" ::"v"(wfrag), "v"(xfrag) : "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223"); break;
-    case 14: asm volatile("v_mfma_f32_32x32x16_bf16 a[224:239], %0, %1, a[224:239]" ::"v"(wfrag), "v"(xfrag) : "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239"); break;
-    case 15: asm volatile("v_mfma_f32_32x32x16_bf16 a[240:255], %0, %1, a[240:255]" ::"v"(wfrag), "v"(xfrag) : "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"); break;
-  }
-}
-// element group g (0..3) of accumulator idx: rows 8 g + 4 (lane >> 5) .. + 3 of the 32 x 32 tile, column lane & 31
-__device__ __forceinline__ f32x4 acc32_read(int idx, int g) {
-  float f0, f1, f2, f3;
-  switch (4 * idx + g) {
-    default: case 0: asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a0", "a1", "a2", "a3"); break;
-    case 1: asm volatile("v_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a5\n\tv_accvgpr_read_b32 %2, a6\n\tv_accvgpr_read_b32 %3, a7" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a4", "a5", "a6", "a7"); break;
-    case 2: asm volatile("v_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9\n\tv_accvgpr_read_b32 %2, a10\n\tv_accvgpr_read_b32 %3, a11" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a8", "a9", "a10", "a11"); break;
-    case 3: asm volatile("v_accvgpr_read_b32 %0, a12\n\tv_accvgpr_read_b32 %1, a13\n\tv_accvgpr_read_b32 %2, a14\n\tv_accvgpr_read_b32 %3, a15" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a12", "a13", "a14", "a15"); break;
-    case 4: asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a16", "a17", "a18", "a19"); break;
-    case 5: asm volatile("v_accvgpr_read_b32 %0, a20\n\tv_accvgpr_read_b32 %1, a21\n\tv_accvgpr_read_b32 %2, a22\n\tv_accvgpr_read_b32 %3, a23" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a20", "a21", "a22", "a23"); break;
-    case 6: asm volatile("v_accvgpr_read_b32 %0, a24\n\tv_accvgpr_read_b32 %1, a25\n\tv_accvgpr_read_b32 %2, a26\n\tv_accvgpr_read_b32 %3, a27" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a24", "a25", "a26", "a27"); break;
-    case 7: asm volatile("v_accvgpr_read_b32 %0, a28\n\tv_accvgpr_read_b32 %1, a29\n\tv_accvgpr_read_b32 %2, a30\n\tv_accvgpr_read_b32 %3, a31" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a28", "a29", "a30", "a31"); break;
-    case 8: asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a32", "a33", "a34", "a35"); break;
-    case 9: asm volatile("v_accvgpr_read_b32 %0, a36\n\tv_accvgpr_read_b32 %1, a37\n\tv_accvgpr_read_b32 %2, a38\n\tv_accvgpr_read_b32 %3, a39" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a36", "a37", "a38", "a39"); break;
-    case 10: asm volatile("v_accvgpr_read_b32 %0, a40\n\tv_accvgpr_read_b32 %1, a41\n\tv_accvgpr_read_b32 %2, a42\n\tv_accvgpr_read_b32 %3, a43" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a40", "a41", "a42", "a43"); break;
-    case 11: asm volatile("v_accvgpr_read_b32 %0, a44\n\tv_accvgpr_read_b32 %1, a45\n\tv_accvgpr_read_b32 %2, a46\n\tv_accvgpr_read_b32 %3, a47" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a44", "a45", "a46", "a47"); break;
-    case 12: asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a48", "a49", "a50", "a51"); break;
-    case 13: asm volatile("v_accvgpr_read_b32 %0, a52\n\tv_accvgpr_read_b32 %1, a53\n\tv_accvgpr_read_b32 %2, a54\n\tv_accvgpr_read_b32 %3, a55" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a52", "a53", "a54", "a55"); break;
-    case 14: asm volatile("v_accvgpr_read_b32 %0, a56\n\tv_accvgpr_read_b32 %1, a57\n\tv_accvgpr_read_b32 %2, a58\n\tv_accvgpr_read_b32 %3, a59" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a56", "a57", "a58", "a59"); break;
-    case 15: asm volatile("v_accvgpr_read_b32 %0, a60\n\tv_accvgpr_read_b32 %1, a61\n\tv_accvgpr_read_b32 %2, a62\n\tv_accvgpr_read_b32 %3, a63" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a60", "a61", "a62", "a63"); break;
-    case 16: asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a64", "a65", "a66", "a67"); break;
-    case 17: asm volatile("v_accvgpr_read_b32 %0, a68\n\tv_accvgpr_read_b32 %1, a69\n\tv_accvgpr_read_b32 %2, a70\n\tv_accvgpr_read_b32 %3, a71" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a68", "a69", "a70", "a71"); break;
-    case 18: asm volatile("v_accvgpr_read_b32 %0, a72\n\tv_accvgpr_read_b32 %1, a73\n\tv_accvgpr_read_b32 %2, a74\n\tv_accvgpr_read_b32 %3, a75" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a72", "a73", "a74", "a75"); break;
-    case 19: asm volatile("v_accvgpr_read_b32 %0, a76\n\tv_accvgpr_read_b32 %1, a77\n\tv_accvgpr_read_b32 %2, a78\n\tv_accvgpr_read_b32 %3, a79" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a76", "a77", "a78", "a79"); break;
-    case 20: asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a80", "a81", "a82", "a83"); break;
-    case 21: asm volatile("v_accvgpr_read_b32 %0, a84\n\tv_accvgpr_read_b32 %1, a85\n\tv_accvgpr_read_b32 %2, a86\n\tv_accvgpr_read_b32 %3, a87" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a84", "a85", "a86", "a87"); break;
-    case 22: asm volatile("v_accvgpr_read_b32 %0, a88\n\tv_accvgpr_read_b32 %1, a89\n\tv_accvgpr_read_b32 %2, a90\n\tv_accvgpr_read_b32 %3, a91" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a88", "a89", "a90", "a91"); break;
-    case 23: asm volatile("v_accvgpr_read_b32 %0, a92\n\tv_accvgpr_read_b32 %1, a93\n\tv_accvgpr_read_b32 %2, a94\n\tv_accvgpr_read_b32 %3, a95" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a92", "a93", "a94", "a95"); break;
-    case 24: asm volatile("v_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\tv_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a96", "a97", "a98", "a99"); break;
-    case 25: asm volatile("v_accvgpr_read_b32 %0, a100\n\tv_accvgpr_read_b32 %1, a101\n\tv_accvgpr_read_b32 %2, a102\n\tv_accvgpr_read_b32 %3, a103" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a100", "a101", "a102", "a103"); break;
-    case 26: asm volatile("v_accvgpr_read_b32 %0, a104\n\tv_accvgpr_read_b32 %1, a105\n\tv_accvgpr_read_b32 %2, a106\n\tv_accvgpr_read_b32 %3, a107" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a104", "a105", "a106", "a107"); break;
-    case 27: asm volatile("v_accvgpr_read_b32 %0, a108\n\tv_accvgpr_read_b32 %1, a109\n\tv_accvgpr_read_b32 %2, a110\n\tv_accvgpr_read_b32 %3, a111" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a108", "a109", "a110", "a111"); break;
-    case 28: asm volatile("v_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\tv_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a112", "a113", "a114", "a115"); break;
-    case 29: asm volatile("v_accvgpr_read_b32 %0, a116\n\tv_accvgpr_read_b32 %1, a117\n\tv_accvgpr_read_b32 %2, a118\n\tv_accvgpr_read_b32 %3, a119" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a116", "a117", "a118", "a119"); break;
-    case 30: asm volatile("v_accvgpr_read_b32 %0, a120\n\tv_accvgpr_read_b32 %1, a121\n\tv_accvgpr_read_b32 %2, a122\n\tv_accvgpr_read_b32 %3, a123" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a120", "a121", "a122", "a123"); break;
-    case 31: asm volatile("v_accvgpr_read_b32 %0, a124\n\tv_accvgpr_read_b32 %1, a125\n\tv_accvgpr_read_b32 %2, a126\n\tv_accvgpr_read_b32 %3, a127" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a124", "a125", "a126", "a127"); break;
-    case 32: asm volatile("v_accvgpr_read_b32 %0, a128\n\tv_accvgpr_read_b32 %1, a129\n\tv_accvgpr_read_b32 %2, a130\n\tv_accvgpr_read_b32 %3, a131" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a128", "a129", "a130", "a131"); break;
-    case 33: asm volatile("v_accvgpr_read_b32 %0, a132\n\tv_accvgpr_read_b32 %1, a133\n\tv_accvgpr_read_b32 %2, a134\n\tv_accvgpr_read_b32 %3, a135" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a132", "a133", "a134", "a135"); break;
-    case 34: asm volatile("v_accvgpr_read_b32 %0, a136\n\tv_accvgpr_read_b32 %1, a137\n\tv_accvgpr_read_b32 %2, a138\n\tv_accvgpr_read_b32 %3, a139" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a136", "a137", "a138", "a139"); break;
-    case 35: asm volatile("v_accvgpr_read_b32 %0, a140\n\tv_accvgpr_read_b32 %1, a141\n\tv_accvgpr_read_b32 %2, a142\n\tv_accvgpr_read_b32 %3, a143" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a140", "a141", "a142", "a143"); break;
-    case 36: asm volatile("v_accvgpr_read_b32 %0, a144\n\tv_accvgpr_read_b32 %1, a145\n\tv_accvgpr_read_b32 %2, a146\n\tv_accvgpr_read_b32 %3, a147" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a144", "a145", "a146", "a147"); break;
-    case 37: asm volatile("v_accvgpr_read_b32 %0, a148\n\tv_accvgpr_read_b32 %1, a149\n\tv_accvgpr_read_b32 %2, a150\n\tv_accvgpr_read_b32 %3, a151" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a148", "a149", "a150", "a151"); break;
-    case 38: asm volatile("v_accvgpr_read_b32 %0, a152\n\tv_accvgpr_read_b32 %1, a153\n\tv_accvgpr_read_b32 %2, a154\n\tv_accvgpr_read_b32 %3, a155" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a152", "a153", "a154", "a155"); break;
-    case 39: asm volatile("v_accvgpr_read_b32 %0, a156\n\tv_accvgpr_read_b32 %1, a157\n\tv_accvgpr_read_b32 %2, a158\n\tv_accvgpr_read_b32 %3, a159" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a156", "a157", "a158", "a159"); break;
-    case 40: asm volatile("v_accvgpr_read_b32 %0, a160\n\tv_accvgpr_read_b32 %1, a161\n\tv_accvgpr_read_b32 %2, a162\n\tv_accvgpr_read_b32 %3, a163" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a160", "a161", "a162", "a163"); break;
-    case 41: asm volatile("v_accvgpr_read_b32 %0, a164\n\tv_accvgpr_read_b32 %1, a165\n\tv_accvgpr_read_b32 %2, a166\n\tv_accvgpr_read_b32 %3, a167" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a164", "a165", "a166", "a167"); break;
-    case 42: asm volatile("v_accvgpr_read_b32 %0, a168\n\tv_accvgpr_read_b32 %1, a169\n\tv_accvgpr_read_b32 %2, a170\n\tv_accvgpr_read_b32 %3, a171" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a168", "a169", "a170", "a171"); break;
-    case 43: asm volatile("v_accvgpr_read_b32 %0, a172\n\tv_accvgpr_read_b32 %1, a173\n\tv_accvgpr_read_b32 %2, a174\n\tv_accvgpr_read_b32 %3, a175" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a172", "a173", "a174", "a175"); break;
-    case 44: asm volatile("v_accvgpr_read_b32 %0, a176\n\tv_accvgpr_read_b32 %1, a177\n\tv_accvgpr_read_b32 %2, a178\n\tv_accvgpr_read_b32 %3, a179" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a176", "a177", "a178", "a179"); break;
-    case 45: asm volatile("v_accvgpr_read_b32 %0, a180\n\tv_accvgpr_read_b32 %1, a181\n\tv_accvgpr_read_b32 %2, a182\n\tv_accvgpr_read_b32 %3, a183" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a180", "a181", "a182", "a183"); break;
-    case 46: asm volatile("v_accvgpr_read_b32 %0, a184\n\tv_accvgpr_read_b32 %1, a185\n\tv_accvgpr_read_b32 %2, a186\n\tv_accvgpr_read_b32 %3, a187" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a184", "a185", "a186", "a187"); break;
-    case 47: asm volatile("v_accvgpr_read_b32 %0, a188\n\tv_accvgpr_read_b32 %1, a189\n\tv_accvgpr_read_b32 %2, a190\n\tv_accvgpr_read_b32 %3, a191" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a188", "a189", "a190", "a191"); break;
-    case 48: asm volatile("v_accvgpr_read_b32 %0, a192\n\tv_accvgpr_read_b32 %1, a193\n\tv_accvgpr_read_b32 %2, a194\n\tv_accvgpr_read_b32 %3, a195" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a192", "a193", "a194", "a195"); break;
-    case 49: asm volatile("v_accvgpr_read_b32 %0, a196\n\tv_accvgpr_read_b32 %1, a197\n\tv_accvgpr_read_b32 %2, a198\n\tv_accvgpr_read_b32 %3, a199" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a196", "a197", "a198", "a199"); break;
-    case 50: asm volatile("v_accvgpr_read_b32 %0, a200\n\tv_accvgpr_read_b32 %1, a201\n\tv_accvgpr_read_b32 %2, a202\n\tv_accvgpr_read_b32 %3, a203" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a200", "a201", "a202", "a203"); break;
-    case 51: asm volatile("v_accvgpr_read_b32 %0, a204\n\tv_accvgpr_read_b32 %1, a205\n\tv_accvgpr_read_b32 %2, a206\n\tv_accvgpr_read_b32 %3, a207" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a204", "a205", "a206", "a207"); break;
-    case 52: asm volatile("v_accvgpr_read_b32 %0, a208\n\tv_accvgpr_read_b32 %1, a209\n\tv_accvgpr_read_b32 %2, a210\n\tv_accvgpr_read_b32 %3, a211" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a208", "a209", "a210", "a211"); break;
-    case 53: asm volatile("v_accvgpr_read_b32 %0, a212\n\tv_accvgpr_read_b32 %1, a213\n\tv_accvgpr_read_b32 %2, a214\n\tv_accvgpr_read_b32 %3, a215" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a212", "a213", "a214", "a215"); break;
-    case 54: asm volatile("v_accvgpr_read_b32 %0, a216\n\tv_accvgpr_read_b32 %1, a217\n\tv_accvgpr_read_b32 %2, a218\n\tv_accvgpr_read_b32 %3, a219" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a216", "a217", "a218", "a219"); break;
-    case 55: asm volatile("v_accvgpr_read_b32 %0, a220\n\tv_accvgpr_read_b32 %1, a221\n\tv_accvgpr_read_b32 %2, a222\n\tv_accvgpr_read_b32 %3, a223" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a220", "a221", "a222", "a223"); break;
-    case 56: asm volatile("v_accvgpr_read_b32 %0, a224\n\tv_accvgpr_read_b32 %1, a225\n\tv_accvgpr_read_b32 %2, a226\n\tv_accvgpr_read_b32 %3, a227" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a224", "a225", "a226", "a227"); break;
-    case 57: asm volatile("v_accvgpr_read_b32 %0, a228\n\tv_accvgpr_read_b32 %1, a229\n\tv_accvgpr_read_b32 %2, a230\n\tv_accvgpr_read_b32 %3, a231" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a228", "a229", "a230", "a231"); break;
-    case 58: asm volatile("v_accvgpr_read_b32 %0, a232\n\tv_accvgpr_read_b32 %1, a233\n\tv_accvgpr_read_b32 %2, a234\n\tv_accvgpr_read_b32 %3, a235" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a232", "a233", "a234", "a235"); break;
-    case 59: asm volatile("v_accvgpr_read_b32 %0, a236\n\tv_accvgpr_read_b32 %1, a237\n\tv_accvgpr_read_b32 %2, a238\n\tv_accvgpr_read_b32 %3, a239" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a236", "a237", "a238", "a239"); break;
-    case 60: asm volatile("v_accvgpr_read_b32 %0, a240\n\tv_accvgpr_read_b32 %1, a241\n\tv_accvgpr_read_b32 %2, a242\n\tv_accvgpr_read_b32 %3, a243" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a240", "a241", "a242", "a243"); break;
-    case 61: asm volatile("v_accvgpr_read_b32 %0, a244\n\tv_accvgpr_read_b32 %1, a245\n\tv_accvgpr_read_b32 %2, a246\n\tv_accvgpr_read_b32 %3, a247" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a244", "a245", "a246", "a247"); break;
-    case 62: asm volatile("v_accvgpr_read_b32 %0, a248\n\tv_accvgpr_read_b32 %1, a249\n\tv_accvgpr_read_b32 %2, a250\n\tv_accvgpr_read_b32 %3, a251" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a248", "a249", "a250", "a251"); break;
-    case 63: asm volatile("v_accvgpr_read_b32 %0, a252\n\tv_accvgpr_read_b32 %1, a253\n\tv_accvgpr_read_b32 %2, a254\n\tv_accvgpr_read_b32 %3, a255" : "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : : "a252", "a253", "a254", "a255"); break;
-  }
-  return f32x4{f0, f1, f2, f3};
-}
-
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), written out: every slot index is a compile-time constant (a
-// 64-trip loop around the 64-case accumulator switches below is too big for the unroller, which then indexes the fragments dynamically)
 template <int... S, typename F>
 __device__ __forceinline__ void for_each_slot(std::integer_sequence<int, S...>, F&& f) {
   (f(std::integral_constant<int, S>{}), ...);
@@ -651,284 +553,18 @@ inline int w4_grid_cap() {
 }
 template <int EPI>
 void launch_w4(const WideArgs& b, hipStream_t st) {
-  static bool done = false;
-  if (!done) {
+  static const bool done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     (void)hipFuncSetAttribute((const void*)gemm_wide256w4_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS);
-    done = true;
-  }
+    return true;
+  }();
+  (void)done;
   const int ntiles = b.tilesM * b.tilesN, n = w4_grid_cap();
   hipLaunchKernelGGL((gemm_wide256w4_kernel<EPI>), dim3(ntiles < n ? ntiles : n), dim3(256), W4_LDS, st, b);
 }
 
 #ifdef HWOCR_DIAG
-// ABL (timing variants, WRONG results; bits): 1 = no DMA inside the loop, 2 = no fragment reads inside the loop, 4 = no swizzle on the DMA source
-template <int ABL>
-__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(WideArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int c = lane & 15, q = lane >> 4;
-  const int wr = w >> 1, wc = w & 1;
-  int tm, tn;
-  tile_of_block(a.tilesM, a.tilesN, 4, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = a.K >> 6;
-
-  // ---- DMA plan: instruction j (0..15) of wave w copies tile rows 8 (16 w + j) .. + 7 of the 512 (256 activation, then 256 weight)
-  const int r8 = lane >> 3, p = lane & 7;
-  // As the vendor kernel issues them: buffer_load ... offen lds with the tile's origin in the buffer resource (scalar), ONE 32-bit
-  // lane offset per instruction that never changes (row * ld + swizzled chunk) and the K tile in the scalar offset - no vector
-  // address arithmetic in the loop.  (Lane offsets are 32 bits: operands up to 2 GiB, which the diagnostic shapes are.)
-  int voff[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int orow = 128 * (w & 1) + 8 * j + r8;  // row of the operand tile (0..255): waves 0, 1 stage the activations, 2, 3 the weights
-    const int lc = (ABL & 4) ? p : p ^ ((orow >> 1) & 7);  // ABL 4: lanes read their row's chunks in address order (LDS image wrong)
-    voff[j] = w < 2 ? (min(m0 + orow, a.M - 1) - m0) * a.ldx * 2 + lc * 16 : (min(n0 + orow, a.N - 1) - n0) * a.ldw * 2 + lc * 16;
-  }
-  const char* origin = w < 2 ? (const char*)a.X + (size_t)m0 * a.ldx * 2 : (const char*)a.W + (size_t)n0 * a.ldw * 2;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0x7fffffff, 0x00020000);
-  const int dst0 = (w < 2 ? 0 : TILE) + (128 * (w & 1)) * 128;  // + j * 1024 (8 rows), lane-linear
-  // (always issued: past the last K tile the last one is copied again into a stage nobody reads any more - no branch around a DMA,
-  // and the counted waits below see the same 16 instructions per tile to the end)
-  auto dma = [&](int t, int j) {
-    if (ABL & 1) {
-      if (t >= 2) return;
-    }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(smem + (t & 1) * STAGE + dst0 + j * 1024), 16, voff[j], min(t, nk - 1) * 128, 0, 0);
-  };
-
-  // ---- fragments: lane (c, q) reads row base + 16 i + c, chunk 4 kk + q
-  const int sw = (c >> 1) & 7;
-  const int xrow0 = (128 * wr + c) * 128;         // + 16 i * 128
-  const int wrow0 = TILE + (128 * wc + c) * 128;  // + 16 j * 128
-  i32x4 xf[2][8], wf[2][8];  // [k-step][tile]
-  auto read_x = [&](const char* st, int kk, int i) { xf[kk][i] = *(const i32x4*)(st + xrow0 + (16 * i) * 128 + (((kk * 4 + q) ^ sw) << 4)); };
-  auto read_w = [&](const char* st, int kk, int j) { wf[kk][j] = *(const i32x4*)(st + wrow0 + (16 * j) * 128 + (((kk * 4 + q) ^ sw) << 4)); };
-
-  {
-    float z = 0.f;
-    asm volatile("" : "+v"(z));
-    for_each_slot(std::make_integer_sequence<int, 64>{}, [&](auto ic) { acc_zero(decltype(ic)::value, z); });
-  }
-
-  // ---- prologue: tiles 0 and 1 requested, tile 0 landed, its k-step-0 fragments read
-#pragma unroll
-  for (int j = 0; j < 16; ++j) dma(0, j);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) dma(1, j);
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  SLOT();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { read_x(smem, 0, i); read_w(smem, 0, i); }
-  if constexpr (ABL & 2) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { read_x(smem, 1, i); read_w(smem, 1, i); }
-  }
-  SLOT();
-
-  auto mma = [&](int kk, int j, int i) { acc_mfma(8 * j + i, __builtin_bit_cast(bf16x8, wf[kk][j]), __builtin_bit_cast(bf16x8, xf[kk][i])); };
-
-  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();
-  for (int t = 0; t < nk; ++t) {
-    const char* st = smem + (t & 1) * STAGE;
-    const char* sn = smem + ((t + 1) & 1) * STAGE;
-    // ---- first half: k-step 0.  Slots 0..31: two MFMAs + one read of a k-step-1 fragment; then wait + barrier; slots after it:
-    // MFMAs with one DMA of tile t + 2 behind every fourth
-    for_each_slot(std::make_integer_sequence<int, 64>{}, [&](auto ic) {
-      constexpr int s = decltype(ic)::value, j = s >> 3, i = s & 7;
-      mma(0, j, i);
-      SLOT();
-      if (s < 16) {  // the 16 reads of the k-step-1 fragments, one behind each of the first 16 MFMAs
-        if constexpr (!(ABL & 2)) {
-          if (s < 8) read_x(st, 1, s);
-          else read_w(st, 1, s - 8);
-        }
-        SLOT();
-      }
-      if (s == 24) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as an instruction the compiler's own wait-count bookkeeping sees (an asm one it does
-        // not: it then re-waits for the same fragments later with counts that also cover newer reads)
-        __builtin_amdgcn_s_barrier();
-        SLOT();
-      }
-      if (s >= 26 && ((s - 26) % 6) == 0) {
-        dma(t + 2, (s - 26) / 6);  // DMAs 0..5 of tile t + 2 behind slots 26, 32, ..., 56
-        SLOT();
-      }
-    });
-    // ---- second half: k-step 1.  DMAs 6..15 of tile t + 2 behind slots 2, 8, ..., 56; the counted wait + barrier behind slot 12 (tile
-    // t + 1 has landed when only the 8 DMAs of tile t + 2 issued so far are outstanding); the 16 reads of tile t + 1's k-step-0
-    // fragments behind slots 13..28 - all of them back long before the loop comes round
-    for_each_slot(std::make_integer_sequence<int, 64>{}, [&](auto ic) {
-      constexpr int s = decltype(ic)::value, j = s >> 3, i = s & 7;
-      mma(1, j, i);
-      SLOT();
-      if ((s % 6) == 2 && s <= 56) {
-        dma(t + 2, 6 + s / 6);
-        SLOT();
-      }
-      if (s == 12) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        SLOT();
-      }
-      if (s >= 13 && s < 29) {  // (past the last tile these read a stage nobody needs: no branch in the stream)
-        if constexpr (!(ABL & 2)) {
-          constexpr int f = s - 13;
-          if (f < 8) read_x(sn, 0, f);
-          else read_w(sn, 0, f - 8);
-        }
-        SLOT();
-      }
-    });
-  }
-  if (tid == 0 && blockIdx.x < 8192) {
-    g_w4_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
-    g_w4_stamps[2 * blockIdx.x + 1] = wall_clock64() - w0;
-  }
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");  // no DMA in flight; the last MFMAs have left the pipe
-  for_each_slot(std::make_integer_sequence<int, 64>{}, [&](auto ic) {
-    constexpr int idx = decltype(ic)::value, j = idx >> 3, i = idx & 7;
-    store_tile<EPI_LINEAR>(a, acc_read(idx), m0 + 128 * wr + 16 * i + c, n0 + 128 * wc + 16 * j + 4 * q);
-  });
-}
-
-
-// ---- the same loop on v_mfma_f32_32x32x16_bf16: 64 MFMAs of 32 cycles per K tile instead of 128 of 16, so that every slot has 24
-// cycles for its filler instead of 8 (a ds_read_b128 or an LDS-DMA issued by a lone wave does not fit in 8: 2700 cycles per K tile in
-// the 16 x 16 form against 2187 for its bare MFMA stream).  A half = two 16-wide k-steps = 32 MFMAs; fragments: lane (r, h) = (lane &
-// 31, lane >> 5) reads row 32 blk + r, chunk 4 half + 2 ks + h.
-template <int ABL>
-__global__ __launch_bounds__(256, 1) void gemm_w4x32_kernel(WideArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int wr = w >> 1, wc = w & 1;
-  int tm, tn;
-  tile_of_block(a.tilesM, a.tilesN, 4, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = a.K >> 6;
-
-  const int r8 = lane >> 3, p = lane & 7;
-  int voff[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int orow = 128 * (w & 1) + 8 * j + r8;
-    const int lc = p ^ ((orow >> 1) & 7);
-    voff[j] = w < 2 ? (min(m0 + orow, a.M - 1) - m0) * a.ldx * 2 + lc * 16 : (min(n0 + orow, a.N - 1) - n0) * a.ldw * 2 + lc * 16;
-  }
-  const char* origin = w < 2 ? (const char*)a.X + (size_t)m0 * a.ldx * 2 : (const char*)a.W + (size_t)n0 * a.ldw * 2;
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0x7fffffff, 0x00020000);
-  const int dst0 = (w < 2 ? 0 : TILE) + (128 * (w & 1)) * 128;
-  auto dma = [&](int t, int j) {
-    if (ABL & 1) {
-      if (t >= 2) return;
-    }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(smem + (t & 1) * STAGE + dst0 + j * 1024), 16, voff[j], min(t, nk - 1) * 128, 0, 0);
-  };
-
-  const int sw = (r >> 1) & 7;
-  const int xrow0 = (128 * wr + r) * 128;         // + 32 blk * 128
-  const int wrow0 = TILE + (128 * wc + r) * 128;
-  i32x4 xf[2][8], wf[2][8];  // [half][4 ks + blk]
-  auto read_x = [&](const char* st, int hf, int f) {
-    xf[hf][f] = *(const i32x4*)(st + xrow0 + (32 * (f & 3)) * 128 + (((4 * hf + 2 * (f >> 2) + h) ^ sw) << 4));
-  };
-  auto read_w = [&](const char* st, int hf, int f) {
-    wf[hf][f] = *(const i32x4*)(st + wrow0 + (32 * (f & 3)) * 128 + (((4 * hf + 2 * (f >> 2) + h) ^ sw) << 4));
-  };
-  {
-    float z = 0.f;
-    asm volatile("" : "+v"(z));
-    for_each_slot(std::make_integer_sequence<int, 64>{}, [&](auto ic) { acc_zero(decltype(ic)::value, z); });
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) dma(0, j);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) dma(1, j);
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  SLOT();
-#pragma unroll
-  for (int f = 0; f < 8; ++f) { read_x(smem, 0, f); read_w(smem, 0, f); }
-  if constexpr (ABL & 2) {
-#pragma unroll
-    for (int f = 0; f < 8; ++f) { read_x(smem, 1, f); read_w(smem, 1, f); }
-  }
-  SLOT();
-  // slot s of a half: ks = s >> 4, jb = (s >> 2) & 3, ib = s & 3
-  auto mma = [&](int hf, int s) {
-    const int ks = s >> 4, jb = (s >> 2) & 3, ib = s & 3;
-    acc32_mfma(4 * jb + ib, __builtin_bit_cast(bf16x8, wf[hf][4 * ks + jb]), __builtin_bit_cast(bf16x8, xf[hf][4 * ks + ib]));
-  };
-  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();
-  for (int t = 0; t < nk; ++t) {
-    const char* st = smem + (t & 1) * STAGE;
-    const char* sn = smem + ((t + 1) & 1) * STAGE;
-    // first half: the 16 reads of the second half's fragments behind slots 0..15, wait + barrier behind slot 19 (stage t & 1 is
-    // free), DMAs 0..3 of tile t + 2 behind slots 20, 23, 26, 29
-    for_each_slot(std::make_integer_sequence<int, 32>{}, [&](auto ic) {
-      constexpr int s = decltype(ic)::value;
-      mma(0, s);
-      SLOT();
-      if (s < 16) {
-        if constexpr (!(ABL & 2)) {
-          if (s < 8) read_x(st, 1, s);
-          else read_w(st, 1, s - 8);
-        }
-        SLOT();
-      }
-      if (s == 19) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as an instruction the compiler's own wait-count bookkeeping sees (an asm one it does
-        // not: it then re-waits for the same fragments later with counts that also cover newer reads)
-        __builtin_amdgcn_s_barrier();
-        SLOT();
-      }
-      if (s >= 20 && ((s - 20) % 3) == 0) {
-        dma(t + 2, (s - 20) / 3);
-        SLOT();
-      }
-    });
-    // second half: DMAs 4..15 behind slots 0, 2, ..., 22; counted wait + barrier behind slot 11 (tile t + 1 landed: 4 + 6 of tile
-    // t + 2 outstanding); the 16 reads of tile t + 1's first-half fragments behind slots 13, 14 and then 16..29
-    for_each_slot(std::make_integer_sequence<int, 32>{}, [&](auto ic) {
-      constexpr int s = decltype(ic)::value;
-      mma(1, s);
-      SLOT();
-      if (s < 24 && !(s & 1)) {
-        dma(t + 2, 4 + s / 2);
-        SLOT();
-      }
-      if (s == 11) {
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        SLOT();
-      }
-      if (s >= 14 && s < 30) {
-        if constexpr (!(ABL & 2)) {
-          constexpr int f = s - 14;
-          if (f < 8) read_x(sn, 0, f);
-          else read_w(sn, 0, f - 8);
-        }
-        SLOT();
-      }
-    });
-  }
-  if (tid == 0 && blockIdx.x < 8192) {
-    g_w4_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
-    g_w4_stamps[2 * blockIdx.x + 1] = wall_clock64() - w0;
-  }
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 7\n\ts_nop 15" ::: "memory");
-  for_each_slot(std::make_integer_sequence<int, 64>{}, [&](auto ic) {
-    constexpr int k = decltype(ic)::value, idx = k >> 2, g = k & 3, jb = idx >> 2, ib = idx & 3;
-    store_tile<EPI_LINEAR>(a, acc32_read(idx, g), m0 + 128 * wr + 32 * ib + r, n0 + 128 * wc + 32 * jb + 8 * g + 4 * h);
-  });
-}
-
-#endif  // HWOCR_DIAG (experimental kernels)
+#include "diag_src/gemm256w4_experiments.inc"  // measurement variants + cycle stamps (tools/bench_gemm_w4.py); never in the product library
+#endif
 
 }  // namespace
 
@@ -973,11 +609,11 @@ extern "C" int hwocr_debug_gemm_w4(const void* X, const void* W, const void* bia
   auto k32 = abl == 1 ? gemm_w4x32_kernel<1> : abl == 2 ? gemm_w4x32_kernel<2> : abl == 3 ? gemm_w4x32_kernel<3> : gemm_w4x32_kernel<0>;
   auto k = form == 32 ? k32 : abl == 1 ? gemm_w4_kernel<1> : abl == 2 ? gemm_w4_kernel<2> : abl == 3 ? gemm_w4_kernel<3> : abl == 4 ? gemm_w4_kernel<4>
            : abl == 6 ? gemm_w4_kernel<6> : gemm_w4_kernel<0>;
-  static bool done = false;
-  if (!done) {
+  static const bool done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    done = true;
-  }
+    return true;
+  }();
+  (void)done;
   hipLaunchKernelGGL(k, dim3(a.tilesM * a.tilesN), dim3(256), LDS_BYTES, stream, a);
   return hwocr_launch_status();
 }

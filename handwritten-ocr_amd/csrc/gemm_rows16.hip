@@ -243,11 +243,11 @@ __global__ __launch_bounds__(64 * R16_WAVES) void gemm_rows16_kernel(Rows16Args 
 template <int EPI, int NC>
 int launch_rows16_nc(const Rows16Args& a, dim3 grid, hipStream_t st) {
   const int lds = R16_RED + (NC ? 16 * (2 * a.K + 16) : 0);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static const bool attr_done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     (void)hipFuncSetAttribute((const void*)gemm_rows16_kernel<EPI, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+    return true;
+  }();
+  (void)attr_done;
   hipLaunchKernelGGL((gemm_rows16_kernel<EPI, NC>), grid, dim3(64 * R16_WAVES), lds, st, a);
   return hwocr_launch_status();
 }

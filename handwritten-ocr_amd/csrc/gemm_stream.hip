@@ -409,11 +409,11 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_stream256_kernel(StreamArgs a
 template <int EPI>
 void launch256(const StreamArgs& a, dim3 grid, hipStream_t st) {
   constexpr int LDS = 4 * (16 + WG_TILES) * 1024;
-  static bool done = false;
-  if (!done) {
+  static const bool done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     (void)hipFuncSetAttribute((const void*)gemm_stream256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    done = true;
-  }
+    return true;
+  }();
+  (void)done;
   hipLaunchKernelGGL((gemm_stream256_kernel<EPI>), grid, dim3(64 * WAVES), LDS, st, a);
 }
 
@@ -421,12 +421,12 @@ template <int MT, int EPI, int MSPLIT, int WT, bool W8>
 void launch_one(const StreamArgs& a, dim3 grid, hipStream_t st) {
   constexpr int STAGE = 2 * MT * 1024 + WT * (W8 ? 1024 : 2048);
   constexpr int LDS = stream_stages(MT, WT, W8) * STAGE;
-  static bool done = false;
-  if (!done) {
+  static const bool done = [&] {  // thread-safe one-time setup: two lane threads reach a kernel's first launch together
     (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<MT, EPI, MSPLIT, WT, W8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDS);
-    done = true;
-  }
+    return true;
+  }();
+  (void)done;
   hipLaunchKernelGGL((gemm_stream_kernel<MT, EPI, MSPLIT, WT, W8>), grid, dim3(64 * WAVES), LDS, st, a);
 }
 
@@ -480,19 +480,19 @@ int plan_stream(int Bsz, int N, int K, int epi, int splitk, bool w8, StreamPlan&
   while ((units + groups - 1) / groups > per_wg) ++groups;
   p.grid = dim3(groups, splitk);
   const int mt = (Bsz + 15) / 16;
-  static const int split8 = [] { const char* e = getenv("HWOCR_STREAM_MSPLIT"); return e ? atoi(e) : 2; }();
+  static const int split8 = HWOCR_DIAG_ENV_INT("HWOCR_STREAM_MSPLIT", 2);
   if (mt <= 1) { p.kind = SK_MT1; return HWOCR_OK; }
   if (mt <= 2) { p.kind = SK_MT2; return HWOCR_OK; }
   if (mt <= 4) { p.kind = SK_MT4; return HWOCR_OK; }
   if (mt <= 8) { p.kind = split8 == 2 ? SK_MT8_M2 : SK_MT8_M1; return HWOCR_OK; }
   // 129..256 rows.  A workgroup that owns at most 10 weight tiles (every decoder GEMM of the 2B / 3B / 7B shapes; not the LM
   // head) takes the 64-wide-K form; HWOCR_STREAM_K64=0: always the 32-wide-K kernel
-  static const bool k64 = [] { const char* e = getenv("HWOCR_STREAM_K64"); return !e || atoi(e) != 0; }();
+  static const bool k64 = HWOCR_DIAG_ENV_INT("HWOCR_STREAM_K64", 1) != 0;
   const int tiles_per_wg = ((units + groups - 1) / groups) * unit;
   // What a workgroup pulls in per K tile is cache lines: 16 rows-tiles x 16 lines of x + 16 lines per weight tile.  Below 8
   // tiles per workgroup two row blocks of 128 (grid.z = 2, half as many tile groups, so twice the tiles each) need fewer:
   // 128 + 32 t against 256 + 16 t lines (2B gate/up: 268 vs 326).  HWOCR_STREAM_R2=0 disables.
-  static const bool r2 = [] { const char* e = getenv("HWOCR_STREAM_R2"); return !e || atoi(e) != 0; }();
+  static const bool r2 = HWOCR_DIAG_ENV_INT("HWOCR_STREAM_R2", 1) != 0;
   if (k64 && r2 && tiles_per_wg < 8) {
     int g2 = 256 / (2 * splitk);  // never more than one round of workgroups (a few left over for a second round cost a whole trip count)
     if (g2 < 1) g2 = 1;

@@ -187,7 +187,7 @@ extern "C" int hwocr_vit_forward(const hwocr_vit* m, const hwocr_vit_ws* ws, con
                           HWOCR_EPI_LINEAR, st));
   }
   const float scale = 1.0f / sqrtf((float)(D / m->heads));
-  static const bool fuse_env = [] { const char* e = getenv("HWOCR_VIT_FUSE_QKV"); return !e || atoi(e) != 0; }();
+  static const bool fuse_env = HWOCR_DIAG_ENV_INT("HWOCR_VIT_FUSE_QKV", 1) != 0;
   const bool fuse_qkv = fuse_env && m->qk_interleaved && (rows % 64) == 0 && hwocr_vit_qkv_fusable(rows, m->heads, hd);
   for (int l = 0; l < m->depth; ++l) {
     const hwocr_vit_block& b = m->blocks[l];
@@ -328,7 +328,7 @@ static void decode_splits(const hwocr_decoder* m, int nseq, int& s_qkv, int& s_o
 
 // HWOCR_DECODE_LASTWG=0: split attention partials are merged, and the token picked, by launches of their own (A/B runs)
 static bool decode_lastwg() {
-  static const bool on = [] { const char* e = getenv("HWOCR_DECODE_LASTWG"); return !e || atoi(e) != 0; }();
+  static const bool on = HWOCR_DIAG_ENV_INT("HWOCR_DECODE_LASTWG", 1) != 0;
   return on;
 }
 
@@ -348,7 +348,7 @@ static int decode_select(const hwocr_decoder* m, const hwocr_dec_ws* ws, const h
 // <= 16 reads in flight and every layer GEMM with its bf16 fragment-tiled copy (no E4M3 decode weights): the 5-launch layer of
 // csrc/gemm_rows16.hip.  HWOCR_DECODE_ROWS16=0: the general path at every read count (A/B runs).
 static bool decode_takes_rows16(const hwocr_decoder* m, int nseq) {
-  static const bool on = [] { const char* e = getenv("HWOCR_DECODE_ROWS16"); return !e || atoi(e) != 0; }();
+  static const bool on = HWOCR_DIAG_ENV_INT("HWOCR_DECODE_ROWS16", 1) != 0;
   if (!on || nseq > 16 || m->hidden > 4096 || (m->hidden % 32) || (m->inter % 32) || ((m->Hq * m->head_dim) % 32)) return false;
   for (int l = 0; l < m->layers; ++l) {
     const hwocr_dec_layer& L = m->L[l];
@@ -366,6 +366,19 @@ static int rows16_down_split(const hwocr_decoder* m) {
   if (s < 1) s = 1;
   const int per = (ksteps + s - 1) / s;  // every slice must own at least one k-step
   return (ksteps + per - 1) / per;
+}
+
+// fp32 elements hwocr_decode_step writes into ws->slabs at `nseq` reads in flight (hwocr.h): the caller's size contract
+extern "C" long hwocr_decode_slab_floats(const hwocr_decoder* m, int nseq) {
+  if (!m || nseq <= 0 || nseq > 256 || !m->L) return -1;
+  const long HD = m->head_dim, Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD;
+  if (decode_takes_rows16(m, nseq)) return ((long)rows16_down_split(m) * Hd + QW) * nseq;
+  int s_qkv, s_o, s_d;
+  decode_splits(m, nseq, s_qkv, s_o, s_d);
+  long need = s_qkv * QW;
+  if (s_o * Hd > need) need = s_o * Hd;
+  if (s_d * Hd > need) need = s_d * Hd;
+  return need * nseq;
 }
 
 extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv,
@@ -393,9 +406,11 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
       bf16* Vc = B(kv->vt) + l * k_layer;
       hwocr_rows16_norm n1{hbuf[cur], hbuf[cur ^ 1], Hd, l ? ws->slabs : nullptr, l ? sd16 : 0, (long)nseq * Hd, Hd, L.in_norm_w, m->eps, G};
       cur ^= 1;
-      // the QKV projection leaves ONE fp32 slab (in ws->qkv: ws->slabs still holds the down projection's) for the attention launch
-      CHECK(hwocr_gemm_rows16(nullptr, 0, L.qkv_wt, ws->qkv, QW, nseq, QW, Hd, HWOCR_EPI_PARTIAL, 1, &n1, st));
-      CHECK(hwocr_attn_decode_qkv((const float*)ws->qkv, 1, (long)nseq * QW, L.qkv_b, Kc, Vc, gs->lens, gs->rope_delta, m->rope_cos,
+      // the QKV projection leaves ONE fp32 slab for the attention launch, BEHIND the down projection's sd16 slabs in ws->slabs (which
+      // the next layer's norm prologue still reads): (sd16 * hidden + QW) * nseq floats in all - hwocr_decode_slab_floats
+      float* qkv_slab = ws->slabs + (long)sd16 * nseq * Hd;
+      CHECK(hwocr_gemm_rows16(nullptr, 0, L.qkv_wt, qkv_slab, QW, nseq, QW, Hd, HWOCR_EPI_PARTIAL, 1, &n1, st));
+      CHECK(hwocr_attn_decode_qkv(qkv_slab, 1, (long)nseq * QW, L.qkv_b, Kc, Vc, gs->lens, gs->rope_delta, m->rope_cos,
                                   m->rope_sin, ws->attn, ws->part_o, ws->part_ml, decode_lastwg() ? ws->arrive : nullptr, nseq, m->Hq, m->Hkv, attn_splits, k_seq, k_head,
                                   k_seq, k_head, kv->ctx, scale, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
       CHECK(hwocr_gemm_rows16(ws->attn, OW, L.o_wt, hbuf[cur], Hd, nseq, Hd, OW, HWOCR_EPI_RESIDUAL, 1, nullptr, st));
@@ -420,7 +435,7 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
     CHECK(decode_gemm(ws->hn, L.qkv_w, L.qkv_wt, L.qkv8t, L.qkv8.scale, ws->slabs, nseq, QW, Hd, QW, HWOCR_EPI_PARTIAL, s_qkv, st));
     // bias + rotary + cache append of this step's q / k / v ride in the attention launch (one launch per layer less;
     // HWOCR_DECODE_FUSE_QKV=0: the two separate launches, for A/B runs)
-    static const bool fuse_qkv = [] { const char* e = getenv("HWOCR_DECODE_FUSE_QKV"); return !e || atoi(e) != 0; }();
+    static const bool fuse_qkv = HWOCR_DIAG_ENV_INT("HWOCR_DECODE_FUSE_QKV", 1) != 0;
     if (!fuse_qkv) {
       CHECK(hwocr_decode_qkv_finish(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, ws->q, Kc, Vc, gs->lens, gs->rope_delta,
                                     m->rope_cos, m->rope_sin, nseq, m->Hq, m->Hkv, k_seq, k_head, k_seq, k_head,

@@ -371,14 +371,9 @@ def pick_attn_splits(reads: int, kv_heads: int) -> int:
 DECODE_GEMMS = ("qkv", "o", "gate_up", "down", "lm_head")
 
 
-def decode_plan(cfg: ModelConfig, reads: int, fp8: bool = False, attn_splits: int = 0) -> dict:
-    """Kernel instances one decode step of `cfg` runs at `reads` reads in flight, as hwocr_decode_step itself lists them under plan
-    recording (hwocr_plan_begin; one decoder layer + the LM head + the token selection; nothing is launched): {gemm name: (N, K, epi,
-    splitk, variant)} for the five GEMMs, "attn": the attention instance, "launches": every line.  fp8: the engine was built with
-    E4M3 decode weights (fp8 + fp8_decode).  Host-only."""
-    import re
-
-    lib = _lib.hip()
+def _placeholder_decoder(cfg: ModelConfig, fp8: bool = False):
+    """A hwocr_decoder of `cfg`'s shape (one layer) whose pointers are placeholders: what the host-only entry points of the library
+    (plan recording, hwocr_decode_slab_floats) need.  Returns (decoder, the placeholder pointer, objects to keep alive)."""
     layer = (_lib.DecLayer * 1)()
     one = C.c_void_p(64)  # non-NULL: the engine always binds one tiled copy of every decode weight
     for f in ("in_norm_w", "qkv_w", "o_w", "post_norm_w", "gate_up_w", "down_w"):
@@ -397,6 +392,28 @@ def decode_plan(cfg: ModelConfig, reads: int, fp8: bool = False, attn_splits: in
         dec.lm_head8t = _lib.W8(w=one, scale=one)
     else:
         dec.lm_head_t = one
+    return dec, one, (layer,)
+
+
+def decode_slab_floats(cfg: ModelConfig, reads: int, fp8: bool = False) -> int:
+    """fp32 elements a decode step at `reads` reads in flight writes into the workspace's split-K slab buffer
+    (hwocr_decode_slab_floats: the size contract of hwocr_dec_ws.slabs).  Host-only."""
+    dec, _, _keep = _placeholder_decoder(cfg, fp8)
+    n = int(_lib.hip().hwocr_decode_slab_floats(C.byref(dec), reads))
+    if n < 0:
+        raise _lib.HwocrError(f"hwocr_decode_slab_floats refused reads={reads}")
+    return n
+
+
+def decode_plan(cfg: ModelConfig, reads: int, fp8: bool = False, attn_splits: int = 0) -> dict:
+    """Kernel instances one decode step of `cfg` runs at `reads` reads in flight, as hwocr_decode_step itself lists them under plan
+    recording (hwocr_plan_begin; one decoder layer + the LM head + the token selection; nothing is launched): {gemm name: (N, K, epi,
+    splitk, variant)} for the five GEMMs, "attn": the attention instance, "launches": every line.  fp8: the engine was built with
+    E4M3 decode weights (fp8 + fp8_decode).  Host-only."""
+    import re
+
+    lib = _lib.hip()
+    dec, one, _keep = _placeholder_decoder(cfg, fp8)
     ws = _lib.DecWs(**{k: one for k in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "arrive", "select_ws", "logits")})
     kv = _lib.Kv(k=one, vt=one, nseq_max=max(reads, 1), ctx=2048, tiled=1 if cfg.head_dim == 128 else 0)
     eos = (C.c_int * 4)(0, 0, 0, 0)
@@ -826,6 +843,10 @@ class ReadEngine:
             if self.fp8:  # E4M3 staging of one prefill GEMM input + its row scales
                 self._bufs["q8"] = torch.empty(rows * max(c.hidden, c.q_heads * HD, c.inter), dtype=torch.uint8, device=dev)
                 self._bufs["q8s"] = torch.empty(rows, dtype=torch.float32, device=dev)
+            for n in {1, min(16, R), min(17, R), R}:   # the library's own statement of what a step writes there (hwocr.h)
+                need = int(self.lib.hwocr_decode_slab_floats(C.byref(self.dec), n))
+                if need < 0 or need > slab_elems:
+                    raise _lib.HwocrError(f"decode slab buffer: {slab_elems} fp32 allocated, a step at {n} reads writes {need}")
             self._ws_rows = rows
             self._ws_dec = _lib.DecWs(**{k: _lib.ptr(v) for k, v in self._bufs.items()})
             self._drop_graphs()  # graphs bake workspace pointers

@@ -27,3 +27,11 @@ def make_page(seed: int, h: int = 1024, w: int = 1024, ruled: bool = True) -> np
             d.line(pts, fill=(ink, ink, ink), width=int(rng.integers(2, 5)))
             x += 4 * n + int(rng.integers(6, 18))
     return np.asarray(img)
+
+
+def tint_page(page: np.ndarray, tint) -> np.ndarray:
+    """Paper colour: every channel scaled by tint[c] / 256 in integer arithmetic (the same bytes on any host).  The scribbles of
+    make_page differ from page to page only patch by patch; a tint gives a page a GLOBAL look as well, as scanned or
+    photographed paper has (tests/golden/trained_*: what the briefly trained tiny checkpoints tell their pages apart by)."""
+    t = np.asarray(tint, dtype=np.uint16).reshape(1, 1, 3)
+    return ((page.astype(np.uint16) * t) >> 8).astype(np.uint8)

@@ -38,7 +38,7 @@ typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
 #define HWOCR_EPI_GELU_TANH 6 /* nn.GELU(approximate="tanh"): SigLIP MLP (HF siglip/modeling_siglip.py:310-322) */
 #define HWOCR_EPI_GEGLU 7     /* SWIGLU's interleaved tile pairs with the tanh GELU as gate: Gemma MLP (HF gemma/modeling_gemma.py:84-97) */
 
-#define HWOCR_ABI_VERSION 12 /* bumped whenever a signature or struct layout below changes */
+#define HWOCR_ABI_VERSION 13 /* bumped whenever a signature or struct layout below changes */
 int hwocr_abi_version(void);
 /* text of the most recent launch failure in this process ("" if none): launcher name + HIP error */
 const char* hwocr_last_error(void);
@@ -314,8 +314,10 @@ typedef struct { /* KV cache: K [layer][seq][Hkv][ctx][128], VT [layer][seq][Hkv
 } hwocr_kv;
 
 typedef struct {
-  void *h, *hn, *qkv, *q, *attn, *act;   /* bf16 [rows][...] */
-  float *slabs;                           /* fp32 split-K slabs (decode) */
+  void *h, *hn, *qkv, *q, *attn, *act;   /* bf16 [rows][...]: hidden, hidden, (Hq + 2 Hkv) * head_dim, Hq * head_dim, Hq * head_dim, inter wide;
+                                          * rows = nseq * rows_per_seq for hwocr_prefill, nseq for hwocr_decode_step (which does not touch qkv) */
+  float *slabs;                           /* fp32 split-K slabs of a decode step: at least hwocr_decode_slab_floats(m, nseq) elements for every
+                                          * nseq the workspace is used with (at <= 16 reads the QKV slab sits behind the down projection's) */
   float *part_o, *part_ml;                /* decode attention partials */
   int *arrive;                            /* [nseq_max][Hkv] arrival counters of hwocr_attn_decode, zero-initialised (or NULL: merge launch) */
   int *select_ws;                         /* [nseq_max][HWOCR_SELECT_WS_INTS] of hwocr_argmax_advance, zero-initialised (or NULL) */
@@ -350,6 +352,11 @@ int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv
 /* one greedy token for every read in flight (reads 0..nseq-1 of the cache) */
 int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv, const hwocr_gen_state* st,
                       int nseq, int attn_splits, hwocr_stream_t stream);
+
+/* fp32 elements hwocr_decode_step writes into ws->slabs at nseq reads in flight for this decoder (split-K slabs of the QKV / o / down
+ * projections; at <= 16 reads the down projection's slabs AND the QKV slab behind them).  Host only, touches no device memory;
+ * -1 on bad arguments.  A workspace must hold the maximum over every nseq it is used with. */
+long hwocr_decode_slab_floats(const hwocr_decoder* m, int nseq);
 
 /* Plan recording: between hwocr_plan_begin() and hwocr_plan_end() every launcher of this library called on the SAME thread checks
  * its arguments as usual, records one text line "<kernel instance> <geometry>" and returns HWOCR_OK without touching the device

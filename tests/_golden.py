@@ -47,3 +47,32 @@ def tiny_ref_config(family="qwen2_vl"):
                      mrope_section=tuple(t["rope_parameters"]["mrope_section"]), eps=t["rms_norm_eps"],
                      image_token_id=m["image_token_id"], vision_start_id=m["vision_start_token_id"],
                      vision_end_id=m["vision_end_token_id"], tie=True, eos_ids=(m["eos"],), pad_id=m["pad"], **tower)
+
+
+# ------------------------------------------------------------------------------------------------ trained tiny checkpoints
+TRAINED = {"qwen2_vl": "trained_qwen2vl", "qwen2_5_vl": "trained_qwen25vl"}
+
+
+def trained_meta(family="qwen2_vl"):
+    """tests/golden/trained_*.json: HF's own transcriptions (token streams + decoded text) of 8 synthetic pages by the briefly
+    trained tiny checkpoint in tests/golden/trained_*/ (tools/make_goldens.py --only trained,trained25)."""
+    return load_json(TRAINED[family] + ".json")
+
+
+def trained_dir(family="qwen2_vl"):
+    return os.path.join(GOLD, TRAINED[family])
+
+
+def trained_page(case):
+    """The page a fixture case was transcribed from (regenerated: synth.make_page + its paper colour)."""
+    from handwritten_ocr_amd.synth import make_page, tint_page
+
+    return tint_page(make_page(case["page_seed"], *case["page_hw"]), case["page_tint"])
+
+
+def mean_cer(want_texts, got_texts):
+    """The reference's metric over a set of pages: cer() per page (ocr_agent/tools.py:103-118, restated bit-exactly in
+    handwritten_ocr_amd.text and pinned by text_kats.json), averaged."""
+    from handwritten_ocr_amd import text
+
+    return sum(text.cer(w, g) for w, g in zip(want_texts, got_texts)) / len(want_texts)

@@ -57,3 +57,19 @@ def test_abi_version_and_structs():
         assert int(got[cname]) == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
+
+
+def test_the_shipped_library_reads_one_environment_switch_and_a_gpu_test_walks_it():
+    """kernel paths that no test runs must not be selectable from the environment.  The A/B switches of concluded
+    experiments compile only into the -DHWOCR_DIAG library (csrc/common.h: HWOCR_DIAG_ENV_INT); the product library keeps the names
+    listed here, each of which a `-m gpu` test sets."""
+    build.build_all()
+    with open(build.HIP_LIB, "rb") as f:
+        blob = f.read()
+    names = {n.decode() for n in re.findall(rb"HWOCR_[A-Z0-9_]{3,}", blob)}
+    names -= {n for n in names if n.startswith(("HWOCR_STATUS_", "HWOCR_EPI_", "HWOCR_ABI_", "HWOCR_SELECT_"))}   # (constants in messages)
+    assert names == {"HWOCR_VIT80_KERNEL"}, names
+    assert b"getenv" in blob
+    gpu_tests = open(os.path.join(ROOT, "tests", "test_ops_gpu.py")).read()
+    for n in names:
+        assert f'setenv("{n}"' in gpu_tests, f"{n} is read by the library but no GPU test sets it"

@@ -27,6 +27,23 @@ def _attn_variant(nsplit, hd, tiled):
     return buf.value.decode()
 
 
+def _attn_plan_variant(nsplit, hd, tiled, arrive):
+    """The instance name hwocr_attn_decode itself notes for a call (plan recording: nothing is launched) - with arrival counters
+    (the last workgroup merges: "+lastwg") or without (a merge launch: "+merge").  What the launcher says, not a rewritten string."""
+    lib = _lib.hip()
+    one = C.c_void_p(64)
+    Hq, Hkv, ctx, B = (8, 1, 1280, 4) if hd == 256 else (12, 2, 2048, 4)
+    assert lib.hwocr_plan_begin() == 0
+    rc = lib.hwocr_attn_decode(one, one, one, one, one, one, one, one if arrive else None, B, Hq, Hkv, nsplit, Hkv * ctx * hd, ctx * hd,
+                               Hkv * hd * ctx, hd * ctx, ctx, hd ** -0.5, hd, tiled, None)
+    need = C.c_int()
+    lib.hwocr_plan_end(None, 0, C.byref(need))
+    buf = C.create_string_buffer(need.value)
+    lib.hwocr_plan_end(buf, len(buf), C.byref(need))
+    assert rc == 0
+    return buf.value.decode().split("\n")[0].split(" ")[0]
+
+
 def _rows16_variant(B, N, K, epi, splitk, norm, nslab, gemma):
     """The instance + path class hwocr_gemm_rows16 notes for a call (plan recording: nothing is launched)."""
     lib = _lib.hip()
@@ -54,11 +71,17 @@ def _covered():
             gemm.add(_gemm_variant(B, N, K, 5, 1))
     for B in (3, 48, 96, 252):
         gemm |= {_gemm_variant(B, 3584, 1536, 4, 1), _gemm_variant(B, 3584, 1536, 7, 1)}
-    attn = {_attn_variant(ns, hd, tiled) for (_, _, _, hd, tiled, _, ns) in ops.ATTN_DECODE_BENCH_CASES}
-    attn |= {_attn_variant(ns, hd, tiled) for ns in (1, 4) for hd, tiled in ((128, 0), (128, 1), (256, 0))}
-    # every split case runs twice: partials merged by a second launch, and by the workgroup that arrives last (arrival counters:
-    # test_ops_gpu._same_with_the_last_workgroup_merging) - the form hwocr_decode_step uses
-    attn |= {v[: -len("+merge")] + "+lastwg" for v in attn if v.endswith("+merge")}
+    # every attention parity case runs the call without arrival counters (a merge launch behind a split one) and - split cases, in
+    # test_ops_gpu._same_with_the_last_workgroup_merging - again WITH them (the last workgroup merges: the form hwocr_decode_step
+    # uses); both names come from the launcher's own plan note of exactly those two calls
+    shapes = [(ns, hd, tiled) for (_, _, _, hd, tiled, _, ns) in ops.ATTN_DECODE_BENCH_CASES]
+    shapes += [(ns, hd, tiled) for ns in (1, 4) for hd, tiled in ((128, 0), (128, 1), (256, 0))]
+    attn = set()
+    for ns, hd, tiled in shapes:
+        attn.add(_attn_plan_variant(ns, hd, tiled, arrive=False))
+        assert _attn_variant(ns, hd, tiled) in attn, "hwocr_attn_decode_variant must name what the launcher notes"
+        if ns > 1:
+            attn.add(_attn_plan_variant(ns, hd, tiled, arrive=True))
     return gemm, attn
 
 
@@ -106,3 +129,26 @@ def test_variant_query_rejects_what_the_launcher_rejects():
     assert lib.hwocr_gemm_skinny_variant(8, 2048, 1536, 0, 2, 1, buf, len(buf)) == 1     # split-K without PARTIAL
     assert lib.hwocr_attn_decode_variant(17, 128, 1, buf, len(buf)) == 1
     assert lib.hwocr_attn_decode_variant(1, 256, 1, buf, len(buf)) == 1                  # tiled cache is head_dim 128 only
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+def test_the_slab_buffer_contract(preset):
+    """hwocr_dec_ws.slabs (hwocr.h): a decode step writes hwocr_decode_slab_floats(m, nseq) fp32 there.  Held here (host only) to
+    what the step's own plan says - split-K slabs of the widest slab-producing GEMM; at <= 16 reads the down projection's slabs
+    with the QKV slab behind them (that slab used to go to ws->qkv, a bf16 buffer sized for bf16) - and to the
+    engine's allocation rule (engine.ReadEngine._dec_ws: 40 * max_reads * max(QW, hidden))."""
+    cfg = engine.preset(preset)
+    QW = (cfg.q_heads + 2 * cfg.kv_heads) * cfg.head_dim
+    for fp8 in (False, True):
+        for reads in READS + (2, 24, 128, 129, 256):
+            plan = engine.decode_plan(cfg, reads, fp8=fp8)
+            need = engine.decode_slab_floats(cfg, reads, fp8=fp8)
+            rows16 = "gemm_rows16_kernel" in plan["qkv"][4]
+            if rows16:
+                assert need == (plan["down"][3] * cfg.hidden + QW) * reads, (reads, plan["down"], need)
+            else:
+                want = max(plan["qkv"][3] * QW, plan["o"][3] * cfg.hidden, plan["down"][3] * cfg.hidden) * reads
+                assert need == want, (reads, plan["qkv"], plan["o"], plan["down"], need)
+            for max_reads in {reads, 252}:
+                assert need <= 40 * max_reads * max(QW, cfg.hidden)
+    assert _lib.hip().hwocr_decode_slab_floats(None, 4) == -1

@@ -110,3 +110,43 @@ def test_one_batch_at_the_benchs_geometry():
     finally:
         small.close()
         big.close()
+
+
+def test_two_lanes_at_the_benchs_geometry():
+    """`python bench.py`'s own SCHEDULE: two lanes x 252 reads in flight (2 x 14.8 GB of KV + workspaces, 12 pages per tower launch,
+    16 prompts per prefill launch, graph-replayed 252-row decode) — config.schedule claims "same tokens as one batch at a time".
+    Held here at that geometry: four batches of 84 different pages through the two lanes, twice (the second pass replays both lanes'
+    captured graphs), against the same batches one at a time on one lane.  Random-init logits are nearly tied, so this is a
+    determinism statement: the lanes share nothing but the weights, and a launch's result does not depend on what runs beside it."""
+    from handwritten_ocr_amd import engine, gpupre, pipeline, synth
+    from handwritten_ocr_amd.compat import config
+
+    import bench
+
+    cfg = engine.preset("qwen2-vl-2b")
+    sd = engine.random_state_dict(cfg, seed=0, device="cuda")
+    eng = engine.ReadEngine(cfg, sd, max_reads=252, ctx=2048, vit_batch=12, prefill_batch=16)
+    del sd
+    pipe = pipeline.LanePipeline(eng, lanes=2)
+    try:
+        strategies = list(config.PREPROCESSING_STRATEGIES[:3])
+        if not all(gpupre.supported(s) for s in strategies):
+            pytest.skip("OpenCV is importable: the device preprocessing does not restate the cv2 branches")
+        sp = gpupre.StrategyPages("cuda")
+        hw = bench.target_hw(cfg, 1024)
+        n_img = (hw[0] // cfg.patch_size) * (hw[1] // cfg.patch_size) // cfg.merge ** 2
+        prompts = [bench.synthetic_prompt(cfg, n_img)] * 252
+        raws = [torch.from_numpy(np.ascontiguousarray(synth.make_page(700 + p, 1024, 1024))).cuda() for p in range(84)]
+        batches = []
+        for b in range(4):   # batch b: the 84 pages rotated by b, so that no two batches hold the same read in the same slot
+            order = raws[b * 7:] + raws[: b * 7]
+            batches.append([im for raw in order for im in sp.pages(raw, strategies, hw)])
+        n = 8
+        want = [eng.generate(pg, prompts, max_new=n, min_new=n) for pg in batches]
+        assert want[0][0] == want[1][3 * 77] and want[0] != want[1], "the same page reads the same in another slot of another batch"
+        jobs = [(lambda e, hooks, pg=pg: e.generate(pg, prompts, max_new=n, min_new=n, hooks=hooks)) for pg in batches]
+        for _ in range(2):
+            assert pipe.run(jobs) == want
+    finally:
+        pipe.close()
+        eng.close()

@@ -8,8 +8,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests._gpu_util import (DEV, assert_close_bf16, lib, p, randbf, rbf, st, tile_k, tile_v, untile_k,  # noqa: E402
-                             untile_v)
+from tests._gpu_util import (DEV, assert_close_bf16, assert_close_bf16_explained, bf16_neighbours, lib, p, randbf, rbf,  # noqa: E402
+                             st, tile_k, tile_v, untile_k, untile_v)
 
 
 def sync():
@@ -33,6 +33,41 @@ def _epilogue_ref(acc, bias, res, epi):
     if epi == 6:
         return torch.nn.functional.gelu(rbf(v), approximate="tanh")
     raise AssertionError
+
+
+def _activation_candidates(v, epi):
+    """Outcomes of an activation epilogue (epi 2 / 3 / 6) at fp32 pre-activations `v` [n] with every rounded intermediate moved by
+    -1 / 0 / +1 bf16 ulp: x = bf16(acc + bias), and for quick-GELU the rounded gate bf16(sigmoid(bf16(1.702 x))).  [n, 3 or 9]."""
+    xs = bf16_neighbours(rbf(v))                                           # [n, 3]
+    if epi == 2:
+        s = bf16_neighbours(rbf(torch.sigmoid(rbf(1.702 * xs))))           # [n, 3, 3]
+        return (xs.unsqueeze(-1) * s).flatten(1)
+    if epi == 3:
+        return 0.5 * xs * (1.0 + torch.erf(xs / math.sqrt(2.0)))
+    return torch.nn.functional.gelu(xs, approximate="tanh")
+
+
+def _gated_candidates(g_pre, u_pre, geglu):
+    """Outcomes of a gated epilogue at fp32 gate / up pre-activations [n]: gate, activation and up each moved by -1 / 0 / +1 ulp."""
+    gs = bf16_neighbours(rbf(g_pre))                                       # [n, 3]
+    act = torch.nn.functional.gelu(gs, approximate="tanh") if geglu else torch.nn.functional.silu(gs)
+    acts = bf16_neighbours(rbf(act))                                       # [n, 3, 3]
+    us = bf16_neighbours(rbf(u_pre))                                       # [n, 3]
+    return (acts.flatten(1).unsqueeze(-1) * us.unsqueeze(1)).flatten(1)    # [n, 27]
+
+
+def _check_gated(out, acc, bias, geglu, what):
+    """A gated (SwiGLU / GeGLU) output against the fp32 restatement: 3 ulps of |out| * (1 + |gate|) (a 1-ulp flip of the rounded gate
+    g moves silu(g) by up to (1 + |g|) ulps: silu'(g) / silu(g) ~ 1 + 1/g for g << 0) is the hard bound; an element beyond it must
+    be one rounding flip of gate / activation / up away from the reference (assert_close_bf16_explained), at most 1e-6 of the outputs."""
+    M, N = acc.shape
+    pre = acc + (bias.float() if bias is not None else 0.0)
+    a = pre.view(M, N // 32, 2, 16)
+    g_pre, u_pre = a[:, :, 0, :].reshape(M, N // 2), a[:, :, 1, :].reshape(M, N // 2)
+    want = _swiglu_ref(acc, bias, geglu=geglu)
+    gate = rbf(g_pre)
+    return assert_close_bf16_explained(out, want, ulps=3.0, atol=2e-3, what=what, mag=want.abs() * (1.0 + gate.abs()),
+                                       candidates=lambda idx: _gated_candidates(g_pre.flatten()[idx], u_pre.flatten()[idx], geglu))
 
 
 def _swiglu_ref(acc, bias=None, geglu=False):
@@ -65,7 +100,23 @@ WIDE_BENCH_CASES = [
 ]
 
 
-def _check_gemm_wide(M, N, K, epi, ulps=2.0):
+def _check_epilogue(out, acc, bias, res, epi, what):
+    """2 bf16 ulps of the largest rounded intermediate (bf16(acc+bias), the residual) + fp32 accumulation-order noise is the hard
+    bound.  Activation epilogues have three rounding points (bf16(acc + bias), the rounded gate, the output) whose flips can coincide
+    in one element (12 of 3.2e8 outputs at 2.1-2.2 ulps on the first GPU run of the bench-geometry cases): such an element must be
+    EXPLAINED — equal to the epilogue of the reference accumulator with those intermediates moved by one ulp — and stay below 1e-6
+    of the outputs (assert_close_bf16_explained); linear / residual epilogues have no such chain and keep the plain bound."""
+    want = _epilogue_ref(acc, bias, res, epi)
+    mag = (acc + bias.float()).abs() + (res.float().abs() if epi == 1 else 0.0)
+    if epi in (0, 1):
+        assert_close_bf16(out, want, ulps=2.0, atol=2e-3, what=what, mag=mag)
+        return 0
+    v = acc + bias.float()
+    return assert_close_bf16_explained(out, want, ulps=2.0, atol=2e-3, what=what, mag=mag,
+                                       candidates=lambda idx: _activation_candidates(v.flatten()[idx], epi))
+
+
+def _check_gemm_wide(M, N, K, epi):
     x = randbf(M, K, scale=1.0, seed=1)
     w = randbf(N, K, scale=K ** -0.5, seed=2)
     bias = randbf(N, scale=0.5, seed=3)
@@ -75,10 +126,7 @@ def _check_gemm_wide(M, N, K, epi, ulps=2.0):
     assert rc == 0
     sync()
     acc = x.float() @ w.float().t()
-    want = _epilogue_ref(acc, bias, res, epi)
-    # 2 bf16 ulps of the largest rounded intermediate (bf16(acc+bias), the residual) + fp32 accumulation-order noise
-    mag = (acc + bias.float()).abs() + (res.float().abs() if epi == 1 else 0.0)
-    assert_close_bf16(out, want, ulps=ulps, atol=2e-3, what=f"gemm_wide epi={epi}", mag=mag)
+    return _check_epilogue(out, acc, bias, res, epi, f"gemm_wide epi={epi} {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("M,N,K", WIDE_GEMM_SHAPES)
@@ -97,18 +145,16 @@ W4_LOOP_CASES = [(1024, 512, 128, 0), (1024, 512, 192, 0), (1100, 520, 256, 0), 
 
 @pytest.mark.parametrize("M,N,K,epi", W4_LOOP_CASES)
 def test_gemm_wide_four_wave_loop_forms(M, N, K, epi):
-    _check_gemm_wide(M, N, K, epi, ulps=2.0 if epi in (0, 1) else 2.5)
+    _check_gemm_wide(M, N, K, epi)
 
 
 @pytest.mark.parametrize("M,N,K,epi", WIDE_BENCH_CASES)
 def test_gemm_wide_bench_geometry(M, N, K, epi):
     """Every workgroup of the persistent 256 x 256 kernel walks more than one tile (tiles > 256) — against the fp32 product."""
     assert ((M + 255) // 256) * ((N + 255) // 256) > 256
-    # Activations: a 1-ulp flip of x = bf16(acc + bias) (accumulation order) moves x * s by 1 ulp(x), a flip of the rounded gate
-    # s = bf16(sigmoid(bf16(1.702 x))) by x * ulp(s) <= 1 ulp(x) (s in [0.5, 1), x just under a power of two), the output rounding by 0.5 ulp: 2.5 ulps when all three
-    # coincide — which among 3e8 outputs they do (first GPU run of this case: 12 of 318 504 960 elements at 2.1-2.2 ulps, none
-    # beyond).  The small shapes above never meet the coincidence and keep 2 ulps; here the budget is the worst case, 2.5.
-    _check_gemm_wide(M, N, K, epi, ulps=2.0 if epi in (0, 1) else 2.5)
+    # (activation epilogues among 3e8 outputs: a handful of elements land at 2.1-2.2 ulps — three rounding flips coinciding;
+    # _check_epilogue holds each of them to that explanation instead of widening the bound)
+    _check_gemm_wide(M, N, K, epi)
 
 
 # with_bias: the Qwen2.5-VL vision MLP (gate_proj / up_proj carry a bias); (5184, 6912, 1280) is its page shape
@@ -129,13 +175,7 @@ def test_gemm_wide_swiglu(M, N, K, with_bias):
     rc = lib().hwocr_gemm_wide(p(x), p(w), p(bias) if with_bias else None, None, p(out), M, N, K, K, K, N // 2, 0, 4, st())
     assert rc == 0
     sync()
-    acc = x.float() @ w.float().t()
-    want = _swiglu_ref(acc, bias)
-    # a 1-ulp flip of the rounded gate g moves silu(g) by up to (1 + |g|) ulps (silu'(g)/silu(g) ~ 1 + 1/g for g << 0):
-    # the ulp budget is taken at |out| * (1 + |g|)
-    gate = rbf((acc + (bias.float() if with_bias else 0.0)).view(M, N // 32, 2, 16)[:, :, 0, :]).reshape(M, N // 2)
-    # (+0.5 ulp above 1e7 outputs: the budget's four roundings — gate, activation, up, product — all at their worst in one element)
-    assert_close_bf16(out, want, ulps=3.0 if out.numel() < 1e7 else 3.5, atol=2e-3, what="gemm_wide swiglu", mag=want.abs() * (1.0 + gate.abs()))
+    _check_gated(out, x.float() @ w.float().t(), bias, False, f"gemm_wide swiglu {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("M,N,K", WIDE_GEGLU_SHAPES)
@@ -145,11 +185,7 @@ def test_gemm_wide_geglu(M, N, K):
     out = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
     assert lib().hwocr_gemm_wide(p(x), p(w), None, None, p(out), M, N, K, K, K, N // 2, 0, 7, st()) == 0
     sync()
-    acc = x.float() @ w.float().t()
-    gate = rbf(acc.view(M, N // 32, 2, 16)[:, :, 0, :]).reshape(M, N // 2)
-    want = _swiglu_ref(acc, geglu=True)
-    # as the SwiGLU case: a 1-ulp flip of the rounded gate moves the activation by up to (1 + |g|) of its ulps
-    assert_close_bf16(out, want, ulps=3.0 if out.numel() < 1e7 else 3.5, atol=2e-3, what="gemm_wide geglu", mag=want.abs() * (1.0 + gate.abs()))
+    _check_gated(out, x.float() @ w.float().t(), None, True, f"gemm_wide geglu {M}x{N}x{K}")
 
 
 def test_gemm_wide_rejects_bad_shapes():
@@ -1246,10 +1282,7 @@ def test_gemm_wide_fp8(M, N, K, epi):
     assert rc == 0
     sync()
     acc = _fp8_gemm_ref(xq, xs, wq, ws)
-    want = _epilogue_ref(acc, bias, res, epi)
-    mag = (acc + bias.float()).abs() + (res.float().abs() if epi == 1 else 0.0)
-    # activations: 2.5 ulps = the worst case of three coinciding roundings (see test_gemm_wide_bench_geometry)
-    assert_close_bf16(out, want, ulps=2.0 if epi in (0, 1) else 2.5, atol=2e-3, what=f"gemm_wide_fp8 epi={epi}", mag=mag)
+    _check_epilogue(out, acc, bias, res, epi, f"gemm_wide_fp8 epi={epi} {M}x{N}x{K}")   # (2 ulps; explained outliers only)
     # and the quantisation itself stays where E4M3 puts it: a few percent of the bf16 product's spread
     exact = x.float() @ w.float().t()
     assert float((acc - exact).abs().mean() / exact.abs().mean()) < 0.06
@@ -1266,10 +1299,7 @@ def test_gemm_wide_fp8_gated(geglu, M, N, K):
     assert lib().hwocr_gemm_wide_fp8(p(xq), p(xs), p(wq), p(ws), None, None, p(out), M, N, K, K, K, N // 2, 0, 7 if geglu else 4,
                                      st()) == 0
     sync()
-    acc = _fp8_gemm_ref(xq, xs, wq, ws)
-    want = _swiglu_ref(acc, geglu=geglu)
-    gate = rbf(acc.view(M, N // 32, 2, 16)[:, :, 0, :]).reshape(M, N // 2)
-    assert_close_bf16(out, want, ulps=3.0 if out.numel() < 1e7 else 3.5, atol=2e-3, what="gemm_wide_fp8 gated", mag=want.abs() * (1.0 + gate.abs()))
+    _check_gated(out, _fp8_gemm_ref(xq, xs, wq, ws), None, geglu, f"gemm_wide_fp8 gated {M}x{N}x{K}")
 
 
 # ---------------------------------------------------------------------------------------------- E4M3 decode GEMMs (weight-only fp8)

@@ -1,0 +1,142 @@
+"""The accuracy bar of the path on the MI355X: output CER within 0.5 % of the reference's (BASELINE.json `north_star`; metric = `cer`,
+ocr_agent/tools.py:103-118, over the text `generate` returns, tools.py:764-769).
+
+tests/golden/trained_* hold what the real HF classes transcribe — free-running greedy `generate(**inputs, max_new_tokens=128)`
+under the checkpoint's own generation_config, decoded with the checkpoint's tokenizer — from 8 synthetic pages with a briefly
+TRAINED tiny Qwen2-VL / Qwen2.5-VL checkpoint whose greedy choices are decisive (tools/make_goldens.py::make_trained;
+tests/test_trained_oracle.py holds the oracle to the same streams on the CPU).  Here the engine reads the same pages FREE-RUNNING
+through every decode path a shipped configuration takes and the text must stay within CER 0.005 of HF's, page set by page set:
+
+  * <= 16 reads in flight   (gemm_rows16 chain, split attention merged by the last workgroup)
+  * 17..32 reads            (the two-row-tile streaming instance)
+  * 252 reads               (the bench's decode geometry: two 128-row blocks per weight-tile group, one workgroup per (read, kv head))
+  * two lanes               (pipeline.LanePipeline: two batches in flight on two streams)
+  * the drop-in itself      (tools.run_ocr on PNG files with HWOCR_MODEL = the checkpoint directory: chat template, tokenizer,
+                             image processor, continuous batching, detokeniser)
+
+Tolerance: mean CER <= 0.005 over the 8 pages (the bar `north_star` states).  Measured on the first GPU run: see the assertion
+messages / bench.py's `parity_vs_hf_goldens.trained_cer`."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+from tests._golden import FAMILIES, mean_cer, trained_dir, trained_meta, trained_page  # noqa: E402
+
+CER_BAR = 0.005
+
+
+class _Trained:
+    def __init__(self, family):
+        from handwritten_ocr_amd import engine, tokenizer
+        from handwritten_ocr_amd.compat import config
+
+        self.family = family
+        self.meta = trained_meta(family)
+        self.dir = trained_dir(family)
+        cfg, sd = engine.load_checkpoint_dir(self.dir, device="cuda")
+        cfg.min_pixels, cfg.max_pixels = config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS    # tools._load_ocr_model
+        self.cfg = cfg
+        self.eng = engine.ReadEngine(cfg, sd, max_reads=252, ctx=512, vit_batch=12, prefill_batch=16)
+        self.proc = tokenizer.Processor(cfg, tokenizer.HFTokenizer(cfg, self.dir), template_dir=self.dir)
+        self.cases = self.meta["cases"]
+        prepared = [self.proc.prepare(Image.fromarray(trained_page(c), "RGB"), self.meta["prompt"]) for c in self.cases]
+        self.pages = [p for p, _ in prepared]
+        self.prompts = [q for _, q in prepared]
+        for c, q in zip(self.cases, self.prompts):
+            assert q.tolist() == c["input_ids"]
+        self.hf_texts = [c["hf_text"] for c in self.cases]
+        self.n = self.meta["max_new_tokens"]
+
+    def reads(self, count):
+        idx = [i % len(self.cases) for i in range(count)]
+        return idx, [self.pages[i] for i in idx], [self.prompts[i] for i in idx]
+
+    def check(self, idx, streams, what):
+        """CER of the engine's text against HF's, read by read; returns (mean CER, reads whose token stream differs from HF's)."""
+        texts = [self.proc.decode(t, skip_special_tokens=True) for t in streams]
+        want = [self.hf_texts[i] for i in idx]
+        m = mean_cer(want, texts)
+        differing = sum(t != self.cases[i]["hf_tokens"] for i, t in zip(idx, streams))
+        assert m <= CER_BAR, f"{self.family} {what}: mean CER {m:.4f} vs HF's text over {len(idx)} reads ({differing} token streams differ)"
+        return m, differing
+
+
+@pytest.fixture(scope="module", params=FAMILIES)
+def trained(request):
+    t = _Trained(request.param)
+    yield t
+    t.eng.close()
+
+
+def _variants(cfg, reads):
+    from handwritten_ocr_amd import engine
+
+    plan = engine.decode_plan(cfg, reads)
+    return " ".join(str(plan[g][4]) for g in ("qkv", "o", "gate_up", "down")) + " " + plan["attn"]
+
+
+@pytest.mark.parametrize("reads,path", [(8, "gemm_rows16_kernel"), (24, "gemm_stream_kernel<2,"), (252, "rowblocks2")])
+def test_free_running_text_within_the_cer_bar(trained, reads, path):
+    assert path in _variants(trained.cfg, reads), "the case must run the decode path it is named for"
+    idx, pages, prompts = trained.reads(reads)
+    streams = trained.eng.generate(pages, prompts, max_new=trained.n)
+    m, differing = trained.check(idx, streams, f"{reads} reads in flight")
+    # reads of the same page in one batch are the same read
+    for r in range(len(trained.cases), reads):
+        assert streams[r] == streams[r - len(trained.cases)]
+    # the streams HF stopped by EOS stop here too, the others use the whole budget
+    for i, t in zip(idx[:8], streams[:8]):
+        c = trained.cases[i]
+        if differing == 0:
+            assert (t[-1] in trained.cfg.eos_ids) == c["stopped_on_eos"] and len(t) == len(c["hf_tokens"])
+    print(f"[trained {trained.family}] {reads} reads: mean CER {m:.4f}, {differing}/{reads} token streams differ from HF's")
+
+
+def test_two_lanes_within_the_cer_bar(trained):
+    from handwritten_ocr_amd import pipeline
+
+    pipe = pipeline.LanePipeline(trained.eng, lanes=2)
+    try:
+        batches = [trained.reads(n) for n in (24, 8, 40, 24)]
+        jobs = [(lambda e, hooks, p=p, q=q: e.generate(p, q, max_new=trained.n, hooks=hooks)) for _, p, q in batches]
+        for _ in range(2):   # second pass: both lanes replay captured graphs
+            out = pipe.run(jobs)
+            for (idx, _, _), streams in zip(batches, out):
+                trained.check(idx, streams, f"two lanes, batch of {len(idx)}")
+    finally:
+        pipe.close()
+
+
+def test_the_drop_in_transcribes_within_the_cer_bar(trained, tmp_path, monkeypatch, capsys):
+    """tools.run_ocr / run_ocr_batch exactly as ocr_agent/nodes.py calls them, with HWOCR_MODEL naming the checkpoint directory."""
+    from handwritten_ocr_amd import tools
+
+    monkeypatch.setenv("HWOCR_MODEL", trained.dir)
+    monkeypatch.setenv("HWOCR_MAX_READS", "16")
+    monkeypatch.setenv("HWOCR_CTX", "512")
+    monkeypatch.setenv("HWOCR_KEEP_RESIDENT", "0")
+    monkeypatch.setattr(tools, "_ocr_model", None)
+    monkeypatch.setattr(tools, "_ocr_processor", None)
+    paths = []
+    for c in trained.cases:
+        p = tmp_path / f"page{c['page_seed']}.png"
+        Image.fromarray(trained_page(c), "RGB").save(p)
+        paths.append(str(p))
+    params = {"max_new_tokens": trained.n}
+    try:
+        one = tools.run_ocr(paths[0], params)                       # nodes.py:49
+        assert f"Running OCR on {os.path.basename(paths[0])}" in capsys.readouterr().out
+        texts = tools.run_ocr_batch(paths, params)                  # 8 reads in one pass
+        many = tools.run_ocr_batch(paths * 5, params)               # 40 reads through 16 slots, dealt over two lanes, refilled as reads stop
+    finally:
+        tools.unload_ocr_model()
+    assert one == texts[0]
+    m = mean_cer(trained.hf_texts, texts)
+    assert m <= CER_BAR, f"run_ocr_batch: mean CER {m:.4f} vs HF's text"
+    m5 = mean_cer(trained.hf_texts * 5, many)
+    assert m5 <= CER_BAR, f"continuous batching over two lanes: mean CER {m5:.4f}"
+    print(f"[trained {trained.family}] drop-in: mean CER {m:.4f} (8 reads), {m5:.4f} (40 reads through 16 slots)")

@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of one environment switch in ONE gpurun call (same box, same clocks): tools/ab_env.sh NAME "bench args" -> gpurun_out/ab_NAME_{1,0}.json
+# The kernel-path switches exist in the diagnostic library only (-DHWOCR_DIAG): HWOCR_DIAG_LIB=1 makes _lib.hip() build and load it.
 set -e
+export HWOCR_DIAG_LIB=1
 R=${GRAFT_REPO_ROOT:-.}
 mkdir -p $R/gpurun_out
 for round in a b; do
