@@ -20,6 +20,7 @@ import ctypes as C
 import json
 import math
 import os
+import time
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -520,6 +521,42 @@ def wide_plan(cfg: ModelConfig, hw: tuple[int, int], pages: int, reads: int, pro
     return [l for l in buf.value.decode().split("\n") if l]
 
 
+class _IndexView:
+    """seq[idx[0]], seq[idx[1]], ... without touching any item before it is asked for."""
+
+    def __init__(self, seq, idx: list[int]):
+        self.seq, self.idx = seq, idx
+
+    def __len__(self) -> int:
+        return len(self.idx)
+
+    def __getitem__(self, i: int):
+        return self.seq[self.idx[i]]
+
+
+class ReadSource:
+    """The reads of one job that are still waiting for a decode slot, shared by the lanes that work on it: a lane whose slots free up
+    TAKES the next reads (thread-safe), so the lanes stay balanced whatever the reads' lengths, and with reads of equal length the
+    last, short round goes to one lane as one batch instead of leaving every lane half empty (a decode step costs almost the same
+    at 132 rows as at 252: the weights stream either way)."""
+
+    def __init__(self, n: int):
+        import threading
+
+        self.n = n
+        self._next = 0
+        self._lock = threading.Lock()
+
+    def remaining(self) -> int:
+        return self.n - self._next
+
+    def take(self, k: int) -> list[int]:
+        with self._lock:
+            lo = self._next
+            self._next = min(self.n, lo + max(0, k))
+            return list(range(lo, self._next))
+
+
 class ReadEngine:
     VIT_MAX_GRID = 2048  # rows of the vision rotary table: the longest page side in patches (smart_resize admits 200:1 strips:
     #                      sqrt(1024^2 * 200) / 14 = 1035 patches at the reference's max_pixels); encode_pages checks it
@@ -913,22 +950,25 @@ class ReadEngine:
         return other
 
     # ------------------------------------------------------------------------------------------ vision tower
-    def encode_pages(self, pages: list[np.ndarray]) -> tuple[torch.Tensor, list[tuple[int, int, int]], list[np.ndarray]]:
+    def encode_pages(self, pages: list[np.ndarray], shapes: list | None = None) -> tuple[torch.Tensor, list[tuple[int, int, int]], list[np.ndarray]]:
         """uint8 [H, W, 3] pages already at tower resolution -> (embedding buffer [rows][hidden], grids, and for each
         page the buffer row of every image token in prompt (raster) order).  Pages of equal size are batched
         `vit_batch` at a time.  The Qwen2.5-VL tower works in window order from the patch gather on; its rows are never
-        moved back — the row table is the library's `merged[argsort(window_index)]` (HF modeling_qwen2_5_vl.py:474-476)."""
+        moved back — the row table is the library's `merged[argsort(window_index)]` (HF modeling_qwen2_5_vl.py:474-476).
+        `shapes` (optional, (H, W) per page): `pages` is then indexed only when a launch group needs its pages — a lazy sequence
+        (batch._LazyDeviceReads) can still be decoding the later pages while the first groups' tower launches are queued."""
         c = self.cfg
         st = _lib.stream_handle()
         mm = c.merge ** 2
         v25 = c.family == "qwen2_5_vl"
-        grids = [(1, int(p.shape[0]) // c.patch_size, int(p.shape[1]) // c.patch_size) for p in pages]
-        tok_rows: list = [None] * len(pages)
+        shp = [(int(s[0]), int(s[1])) for s in (shapes if shapes is not None else [p.shape for p in pages])]
+        grids = [(1, h // c.patch_size, w // c.patch_size) for h, w in shp]
+        tok_rows: list = [None] * len(shp)
         chunks = []
         total = 0
         by_shape: dict = {}
-        for i, p in enumerate(pages):
-            by_shape.setdefault((int(p.shape[0]), int(p.shape[1])), []).append(i)
+        for i, hw_ in enumerate(shp):
+            by_shape.setdefault(hw_, []).append(i)
         for (H, W), idxs in by_shape.items():
             gh, gw = H // c.patch_size, W // c.patch_size
             if H % (c.patch_size * c.merge) or W % (c.patch_size * c.merge) or gh < 1 or gw < 1:
@@ -972,11 +1012,14 @@ class ReadEngine:
                     self._vit_tables, self._vit_lay = t, lay
                     self._vbufs["patches"].zero_()
                     self._vit_layout = layout
-                if any(isinstance(pages[i], torch.Tensor) for i in group):  # (some) already resident in HBM
-                    imgs = torch.stack([pages[i] if isinstance(pages[i], torch.Tensor) else
-                                        torch.from_numpy(np.ascontiguousarray(pages[i])).to(self.dev) for i in group]).contiguous()
+                items = [pages[i] for i in group]
+                if any(tuple(int(v) for v in it.shape[:2]) != (H, W) for it in items):
+                    raise ValueError(f"a page of this launch group is not {H}x{W} pixels as announced")
+                if any(isinstance(it, torch.Tensor) for it in items):  # (some) already resident in HBM
+                    imgs = torch.stack([it if isinstance(it, torch.Tensor) else
+                                        torch.from_numpy(np.ascontiguousarray(it)).to(self.dev) for it in items]).contiguous()
                 else:
-                    imgs = torch.from_numpy(np.stack([pages[i] for i in group])).to(self.dev, non_blocking=True)
+                    imgs = torch.from_numpy(np.stack(items)).to(self.dev, non_blocking=True)
                 out = torch.empty(rows // mm, c.hidden, dtype=torch.bfloat16, device=self.dev)
                 _lib.check(self.lib.hwocr_vit_forward(C.byref(self.vit), C.byref(ws), _lib.ptr(imgs), n, H, W, Pp,
                                                       C.byref(self._vit_lay), _lib.ptr(out), st), "hwocr_vit_forward")
@@ -1174,19 +1217,25 @@ class ReadEngine:
     # ------------------------------------------------------------------------------------------ continuous batching
     def generate_stream(self, pages: list, prompts: list, max_new: int, min_new: int = 0, sync_every: int = 16,
                         repetition_penalty: float | None = None, min_admit: int = 0, sample: dict | None = None,
-                        read_ids: list | None = None) -> list[list[int]]:
+                        read_ids: list | None = None, on_done=None, source: "ReadSource | None" = None,
+                        max_slots: int = 0) -> list[list[int]]:
         """Reads (greedy or drawn, as `generate`; read i draws from the RNG stream of read number read_ids[i], default i) of ANY number of (page, prompt) pairs through the engine's `max_reads` decode slots, refilled as
         reads finish (EOS or max_new): the lockstep `generate` keeps a whole batch decoding until its longest read is done,
         which with the reference's 2048-token budget (config.py:19) and pages of a few hundred tokens idles most slots.
         Every `sync_every` decode steps the host looks at the stop flags, harvests finished reads, and prefills new ones
         into the freed slots (vision + prefill run while the other slots wait; their KV stays in place) — once at least
         `min_admit` slots are free (default an eighth of the slots: the tower and the prefill GEMMs want rows), or nothing
-        is decoding.  Results are in input order and equal `generate` on each read alone (reads never see each other)."""
+        is decoding.  Results are in input order and equal `generate` on each read alone (reads never see each other).
+        `on_done(i, tokens)` is called (on this thread) as soon as read i is harvested: the batch driver hands finished pages to its
+        gather / writer threads while the remaining reads decode.  `source`: a ReadSource over the same (pages, prompts) shared with
+        other lanes' generate_stream calls — this call then reads what it takes from it, the result list holds None for reads another
+        lane took.  `max_slots`: use at most that many of the engine's decode slots (tools.plan_lanes balances a job over lanes)."""
         c, lib, dev = self.cfg, self.lib, self.dev
         N = len(pages)
         if N == 0:
             return []
-        R = min(self.max_reads, N)
+        R = min(self.max_reads, N, max_slots or self.max_reads)
+        src = source if source is not None else ReadSource(N)
         st = _lib.stream_handle()
         Tmax = max(len(p) for p in prompts)
         if _ceil(Tmax, 64) + max_new + sync_every > self.ctx:
@@ -1215,17 +1264,20 @@ class ReadEngine:
         self.cur_ids[:R].fill_(c.pad_id)
         slot_read = [-1] * R
         results: list = [None] * N
-        nxt = 0
         splits = self.attn_splits or pick_attn_splits(R, c.kv_heads)
         ws = self._dec_ws(max(min(self.prefill_batch, R) * _ceil(Tmax, 64), self.max_reads))
 
         admit_keep: list = []  # device tensors the queued prefill launches read; released after the next synchronisation
 
-        def admit(slots: list[int]) -> None:
-            nonlocal nxt
-            reads = list(range(nxt, nxt + len(slots)))
-            nxt += len(slots)
-            emb, grids, tok_rows = self.encode_pages([pages[r] for r in reads])
+        def admit(slots: list[int]) -> int:
+            reads = src.take(len(slots))
+            if not reads:
+                return 0
+            slots = slots[: len(reads)]
+            if hasattr(pages, "shape_of"):   # a lazy sequence: its items are made when the tower's launch groups reach them
+                emb, grids, tok_rows = self.encode_pages(_IndexView(pages, reads), shapes=[pages.shape_of(r) for r in reads])
+            else:
+                emb, grids, tok_rows = self.encode_pages([pages[r] for r in reads])
             T = [len(prompts[r]) for r in reads]
             Tp = _ceil(max(T), 64)
             n = len(reads)
@@ -1277,12 +1329,17 @@ class ReadEngine:
                 j0 = j1
             for s, r in zip(slots, reads):
                 slot_read[s] = r
+            return len(reads)
 
         key = (R, splits, max_new, min_new, rp, tuple(c.eos_ids), c.pad_id, smp)
+        trace = [] if self.collect_timings else None   # (reads admitted, wall ms) per trip of the loop: where a folder's time goes
         while True:
+            t_trip = time.perf_counter()
+            n_admit = 0
             free = [s for s in range(R) if slot_read[s] < 0]
-            if free and nxt < N and (len(free) >= (min_admit or max(1, R // 8)) or len(free) == R or N - nxt <= len(free)):
-                admit(free[: N - nxt])
+            left = src.remaining()
+            if free and left > 0 and (len(free) >= (min_admit or max(1, R // 8)) or len(free) == R or left <= len(free)):
+                n_admit = admit(free[:left])
             if all(r < 0 for r in slot_read):
                 break
             if key not in self._graphs:
@@ -1311,10 +1368,16 @@ class ReadEngine:
                             seq = seq[: k + 1]
                             break
                     results[slot_read[s]] = seq
+                    if on_done is not None:
+                        on_done(slot_read[s], seq)
                     slot_read[s] = -1
             idle = torch.tensor([s for s in range(R) if slot_read[s] < 0], dtype=torch.long, device=dev)
             if len(idle):  # parked: finished one-token reads at position 0 (their context must not grow with the padding steps)
                 self.finished[idle] = 1
                 self.lens[idle] = 1
                 self.rope_delta[idle] = 0
+            if trace is not None:
+                trace.append((n_admit, (time.perf_counter() - t_trip) * 1e3))
+        if trace is not None:
+            self.stream_trace = trace
         return results

@@ -76,7 +76,7 @@ def _load_ocr_model():
         sd = engine.random_state_dict(cfg, seed=int(os.environ.get("HWOCR_SEED", "0")), device=dev)
         tok = tokenizer.ByteTokenizer(cfg, fold_unknown=True)
     cfg.min_pixels, cfg.max_pixels = config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS
-    _ocr_model = engine.ReadEngine(cfg, sd, max_reads=int(os.environ.get("HWOCR_MAX_READS", "252")),
+    _ocr_model = engine.ReadEngine(cfg, sd, max_reads=int(os.environ.get("HWOCR_MAX_READS", "256")),
                                    ctx=int(os.environ.get("HWOCR_CTX", "4096")), device=dev,
                                    fp8=os.environ.get("HWOCR_FP8", "0") not in ("", "0"))
     _ocr_processor = tokenizer.Processor(cfg, tok, template_dir=spec if os.path.isdir(spec) else None)
@@ -84,31 +84,60 @@ def _load_ocr_model():
     return _ocr_model, _ocr_processor
 
 
-_ocr_lanes = None  # pipeline.LanePipeline over _ocr_model, made on the first batch that has more reads than decode slots
+def _lib_error(msg: str):
+    from . import _lib
+
+    return _lib.HwocrError(msg)
 
 
-def _lanes():
-    """Two (HWOCR_LANES) sets of read slots over the loaded weights, each on its own stream and host thread: a batch with more reads
-    than one lane has slots is dealt over them (pipeline.py: +6 % pages/s on the MI355X, same tokens).  None: one lane."""
-    global _ocr_lanes
-    n = int(os.environ.get("HWOCR_LANES", "2"))
+_ocr_lanes: dict = {}  # lanes -> pipeline.LanePipeline over _ocr_model, made on the first batch that needs that many
+
+
+def plan_lanes(n_reads: int, slots: int, lanes_cfg: int) -> tuple[int, int]:
+    """(lanes, decode slots to use per lane) for a job of n_reads reads on lanes of `slots` decode slots, lanes_cfg = HWOCR_LANES.
+    A job that fits one lane runs on one.  Otherwise the reads make `batches` = ceil(n / slots) slot-fills; two lanes take them side
+    by side in rounds - unless the job is THREE fills (or an odd multiple of three), which three lanes take in one round instead of
+    two lanes in two with the second half empty (a decode step costs nearly the same at 132 rows as at 252, so a half-empty round is
+    lost time: a 256-page folder = 768 reads is exactly 3 x 256).  Short jobs (<= 4 rounds) use equal shares of the slots per round
+    rather than full rounds and a remainder; long ones keep every slot busy (continuous batching refills them)."""
+    batches = -(-n_reads // max(1, slots))
+    if batches <= 1 or lanes_cfg <= 1:
+        return 1, slots
+    lanes = lanes_cfg
+    if lanes_cfg == 2 and batches % 2 == 1 and batches % 3 == 0:
+        lanes = 3
+    rounds = -(-batches // lanes)
+    per = slots if rounds > 4 else min(slots, -(-n_reads // (rounds * lanes)))
+    return lanes, per
+
+
+def _lanes(n: int | None = None):
+    """n (default HWOCR_LANES = 2) sets of read slots over the loaded weights, each on its own stream and host thread: a batch with
+    more reads than one lane has slots goes through them side by side (pipeline.py: +6 % pages/s on the MI355X, same tokens).
+    None: one lane."""
+    n = int(os.environ.get("HWOCR_LANES", "2")) if n is None else n
     if n <= 1 or _ocr_model is None:
         return None
-    if _ocr_lanes is None or _ocr_lanes.engines[0] is not _ocr_model or len(_ocr_lanes.engines) != n:
+    pipe = _ocr_lanes.get(n)
+    if pipe is None or pipe.engines[0] is not _ocr_model:
         from . import pipeline
 
-        if _ocr_lanes is not None:
-            _ocr_lanes.close()
-        _ocr_lanes = pipeline.LanePipeline(_ocr_model, lanes=n)
-    return _ocr_lanes
+        if pipe is not None:
+            pipe.close()
+        pipe = _ocr_lanes[n] = pipeline.LanePipeline(_ocr_model, lanes=n)
+    return pipe
+
+
+def _close_lanes() -> None:
+    for pipe in _ocr_lanes.values():
+        pipe.close()
+    _ocr_lanes.clear()
 
 
 def unload_ocr_model():
-    global _ocr_model, _ocr_processor, _ocr_lanes
+    global _ocr_model, _ocr_processor
     if os.environ.get("HWOCR_KEEP_RESIDENT", "1") == "0" and _ocr_model is not None:
-        if _ocr_lanes is not None:
-            _ocr_lanes.close()
-            _ocr_lanes = None
+        _close_lanes()
         _ocr_model.close()
         _ocr_model = None
         _ocr_processor = None
@@ -119,16 +148,25 @@ def unload_ocr_model():
     print("  [ocr] Model unloaded, memory freed.")
 
 
-def run_ocr_batch_tokens(images: list, params: dict | None = None) -> list[list[int]]:
+def run_ocr_batch_tokens(images: list, params: dict | None = None, on_done=None) -> list[list[int]]:
     """Read many (already preprocessed) pages in one engine batch; the generated token ids of every read (what the
     multi-GPU driver gathers to rank 0, shard.gather_token_streams).  `images`: paths, PIL images, or uint8 [H][W][3] device
-    tensors already at the tower's resolution (gpupre.StrategyPages)."""
+    tensors already at the tower's resolution (gpupre.StrategyPages).  `on_done(i, tokens)`: called as soon as read i has stopped
+    (from the thread that drives its lane - two lanes call it concurrently)."""
     params = params or {}
     model, processor = _load_ocr_model()
     prompt = params.get("prompt", config.OCR_PROMPT)
     max_new = params.get("max_new_tokens", config.OCR_MAX_NEW_TOKENS)
     min_new = params.get("min_new_tokens", 0)
     pages, prompts = [], []
+    if hasattr(images, "image_tokens"):   # batch._LazyDeviceReads: a read's page is made when a lane admits it; its size is known now
+        pages, by_n = images, {}
+        for i in range(len(images)):
+            n = images.image_tokens(i)
+            if n not in by_n:
+                by_n[n] = processor.chat_ids(prompt, n)
+            prompts.append(by_n[n])
+        images = []
     for im in images:
         if hasattr(im, "data_ptr"):  # torch tensor resident in HBM
             pages.append(im)
@@ -142,18 +180,25 @@ def run_ocr_batch_tokens(images: list, params: dict | None = None) -> list[list[
     # (read_ids: the caller's numbering of the reads - it keys the sampling RNG, so that a sampled read does not depend on the shard)
     rp = params.get("repetition_penalty")  # None: the checkpoint's default
     ids = params.get("read_ids")
-    pipe = _lanes() if len(pages) > model.max_reads else None
+    n_lanes, per_lane = plan_lanes(len(pages), model.max_reads, int(os.environ.get("HWOCR_LANES", "2")))
+    pipe = _lanes(n_lanes) if n_lanes > 1 else None
     if pipe is None:
-        return model.generate_stream(pages, prompts, max_new=max_new, min_new=min_new, repetition_penalty=rp, read_ids=ids)
-    # more reads than one lane has slots: contiguous shares of the reads, one per lane, side by side (a read's tokens do not depend
-    # on its lane: the RNG of a sampled read is keyed by the caller's read number)
+        return model.generate_stream(pages, prompts, max_new=max_new, min_new=min_new, repetition_penalty=rp, read_ids=ids,
+                                     on_done=on_done)
+    # more reads than one lane has slots: the lanes work side by side through ONE queue of waiting reads (engine.ReadSource), each
+    # taking the next ones whenever its slots free up (a read's tokens do not depend on its lane: the RNG of a sampled read is keyed
+    # by the caller's read number)
+    from . import engine as _engine
+
     ids = list(range(len(pages))) if ids is None else list(ids)
-    n = len(pipe.engines)
-    cuts = [len(pages) * i // n for i in range(n + 1)]
-    jobs = [(lambda e, hooks, lo=lo, hi=hi: e.generate_stream(pages[lo:hi], prompts[lo:hi], max_new=max_new, min_new=min_new,
-                                                               repetition_penalty=rp, read_ids=ids[lo:hi]))
-            for lo, hi in zip(cuts[:-1], cuts[1:])]
-    return [t for part in pipe.run(jobs) for t in part]
+    src = _engine.ReadSource(len(pages))
+    jobs = [(lambda e, hooks: e.generate_stream(pages, prompts, max_new=max_new, min_new=min_new, repetition_penalty=rp, read_ids=ids,
+                                                on_done=on_done, source=src, max_slots=per_lane)) for _ in pipe.engines]
+    parts = pipe.run(jobs)
+    out = [next((part[i] for part in parts if part[i] is not None), None) for i in range(len(pages))]
+    if any(t is None for t in out):
+        raise _lib_error("a read was taken by no lane")
+    return out
 
 
 def decode_tokens(streams: list) -> list[str]:

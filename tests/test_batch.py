@@ -17,7 +17,14 @@ from handwritten_ocr_amd.synth import make_page
 
 def _script_engine(monkeypatch, fn):
     """fn(images, params) -> list of texts; installed at the token seam the batch driver uses."""
-    monkeypatch.setattr(tools, "run_ocr_batch_tokens", lambda images, params=None: [list(t.encode("utf-8")) for t in fn(images, params)])
+    def tokens(images, params=None, on_done=None):
+        out = [list(t.encode("utf-8")) for t in fn(images, params)]
+        if on_done is not None:            # the engine reports reads as they stop, in any order
+            for i in reversed(range(len(out))):
+                on_done(i, out[i])
+        return out
+
+    monkeypatch.setattr(tools, "run_ocr_batch_tokens", tokens)
     monkeypatch.setattr(tools, "decode_tokens", lambda streams: [bytes(t).decode("utf-8") for t in streams])
 
 

@@ -340,9 +340,10 @@ def test_the_two_decode_paths_agree_within_rounding():
 
 
 def test_run_ocr_batch_deals_reads_over_two_lanes(tmp_path, monkeypatch):
-    """More reads than one lane has decode slots: run_ocr_batch_tokens deals them over two lanes (two streams, two host threads,
-    pipeline.LanePipeline) — same token streams as the single lane, in the caller's order, greedy and sampled (the RNG of a sampled
-    read is keyed by the caller's read number, not by its lane)."""
+    """More reads than one lane has decode slots: run_ocr_batch_tokens hands them to two lanes - three when the job is three
+    slot-fills (tools.plan_lanes) - through one shared queue (two / three streams and host threads, pipeline.LanePipeline) — same
+    token streams as the single lane, in the caller's order, greedy and sampled (the RNG of a sampled read is keyed by the caller's
+    read number, not by its lane)."""
     from handwritten_ocr_amd import tools
     from handwritten_ocr_amd.compat import config
     from handwritten_ocr_amd.synth import make_page
@@ -354,17 +355,21 @@ def test_run_ocr_batch_deals_reads_over_two_lanes(tmp_path, monkeypatch):
     monkeypatch.setenv("HWOCR_KEEP_RESIDENT", "0")
     monkeypatch.setattr(tools, "_ocr_model", None)
     monkeypatch.setattr(tools, "_ocr_processor", None)
-    monkeypatch.setattr(tools, "_ocr_lanes", None)
+    monkeypatch.setattr(tools, "_ocr_lanes", {})
     monkeypatch.setattr(config, "OCR_MIN_PIXELS", 28 * 28)
-    imgs = [Image.fromarray(make_page(60 + i, 70 + 14 * (i % 3), 100), "RGB") for i in range(17)]
+    imgs = [Image.fromarray(make_page(60 + i, 70 + 14 * (i % 3), 100), "RGB") for i in range(20)]
     params = {"max_new_tokens": 10, "min_new_tokens": 3}
     monkeypatch.setenv("HWOCR_LANES", "1")
     want = tools.run_ocr_batch_tokens(imgs, params)
-    assert tools._ocr_lanes is None
+    assert tools._ocr_lanes == {}
     monkeypatch.setenv("HWOCR_LANES", "2")
-    got = tools.run_ocr_batch_tokens(imgs, params)
-    assert tools._ocr_lanes is not None and len(tools._ocr_lanes.engines) == 2
-    assert got == want and len(got) == 17
+    got = tools.run_ocr_batch_tokens(imgs, params)                    # 20 reads / 6 slots: 4 fills -> two lanes, two rounds of 5
+    assert tools.plan_lanes(20, 6, 2) == (2, 5)
+    assert set(tools._ocr_lanes) == {2} and len(tools._ocr_lanes[2].engines) == 2
+    assert got == want and len(got) == 20
+    assert tools.plan_lanes(17, 6, 2) == (3, 6)
+    assert tools.run_ocr_batch_tokens(imgs[:17], params) == want[:17]  # 3 fills: three lanes, one round
+    assert set(tools._ocr_lanes) == {2, 3} and len(tools._ocr_lanes[3].engines) == 3
     assert tools.run_ocr_batch_tokens(imgs[:5], params) == want[:5]   # fits one lane: no dealing
     tools._ocr_model.cfg.do_sample, tools._ocr_model.cfg.temperature, tools._ocr_model.cfg.top_k = True, 1.0, 20
     a = tools.run_ocr_batch_tokens(imgs, params)
@@ -372,7 +377,7 @@ def test_run_ocr_batch_deals_reads_over_two_lanes(tmp_path, monkeypatch):
     b = tools.run_ocr_batch_tokens(imgs, params)
     assert a == b and a != want
     tools.unload_ocr_model()
-    assert tools._ocr_model is None and tools._ocr_lanes is None
+    assert tools._ocr_model is None and tools._ocr_lanes == {}
 
 
 def test_batch_folder_cli_end_to_end(tmp_path, monkeypatch, capsys):
@@ -454,9 +459,9 @@ def test_agent_loop_on_the_real_engine(tmp_path, monkeypatch, capsys):
     agents = {"critic": critic, "editor": lambda t, c: {"corrected_text": t, "changes": []}, "arbitrator": Arb}
     entered = []
 
-    def counting_tokens(images, params=None):
+    def counting_tokens(images, params=None, on_done=None):
         entered.append(len(images))
-        return real_tokens(images, params)
+        return real_tokens(images, params, on_done=on_done)
 
     real_tokens = tools.run_ocr_batch_tokens
     monkeypatch.setattr(tools, "run_ocr_batch_tokens", counting_tokens)

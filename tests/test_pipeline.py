@@ -85,3 +85,21 @@ def test_one_lane_or_one_job_runs_on_the_callers_thread():
         pipeline.LanePipeline(FakeEngine(), lanes=0)
     with pytest.raises(ValueError):
         pipeline.LanePipeline(FakeEngine(), lanes=2, order="sideways")
+
+
+def test_plan_lanes():
+    """tools.plan_lanes: how a job's reads are spread over engine lanes (host logic)."""
+    from handwritten_ocr_amd import tools
+
+    assert tools.plan_lanes(100, 256, 2) == (1, 256)            # fits one lane
+    assert tools.plan_lanes(768, 256, 2) == (3, 256)            # a 256-page folder: three fills, three lanes, ONE round
+    assert tools.plan_lanes(768, 256, 1) == (1, 256)            # HWOCR_LANES=1
+    assert tools.plan_lanes(768, 252, 2) == (2, 192)            # four fills of 252: two balanced rounds of 192 per lane
+    assert tools.plan_lanes(512, 256, 2) == (2, 256)
+    assert tools.plan_lanes(300, 256, 2) == (2, 150)            # one round, equal shares instead of 256 + 44
+    assert tools.plan_lanes(2304, 256, 2) == (3, 256)           # nine fills: three lanes, three rounds
+    lanes, per = tools.plan_lanes(100000, 256, 2)               # long jobs: every slot busy, continuous batching refills
+    assert (lanes, per) == (2, 256)
+    for n in (257, 600, 1000, 5000):
+        lanes, per = tools.plan_lanes(n, 256, 2)
+        assert 1 <= per <= 256 and lanes in (2, 3)

@@ -66,10 +66,12 @@ def test_shard_helpers_single_process():
 # ---------------------------------------------------------------------------------------------------------------------------
 # The batch-folder driver over 2 ranks (gloo): every rank reads its share with a scripted engine, rank 0 gathers the token
 # streams and writes ALL pages' files; the files must equal those of the 1-rank run byte for byte.
-def _scripted_tokens(images, params=None):
+def _scripted_tokens(images, params=None, on_done=None, long=False):
     """Deterministic 'reads': the text depends only on the pixels handed to the engine (so it is the same whichever rank
-    reads the page), with lengths that differ per read (ragged gather)."""
+    reads the page), with lengths that differ per read (ragged gather).  Reads are reported (on_done) out of order, a few at a time
+    with a pause between, as an engine's decode slots release them.  `long`: page-length texts (~1.5 k characters)."""
     import hashlib
+    import time
 
     import numpy as np
 
@@ -77,41 +79,68 @@ def _scripted_tokens(images, params=None):
     for im in images:
         h = hashlib.sha1(np.asarray(im).tobytes()).hexdigest()
         words = [h[i: i + 4] for i in range(0, 4 * (3 + int(h[0], 16) % 5), 4)]
+        if long:
+            words = [h[(7 * i) % 36: (7 * i) % 36 + 2 + i % 5] for i in range(300)]
         out.append(list(" ".join(words).encode("utf-8")))
+    if on_done is not None:
+        order = sorted(range(len(out)), key=lambda i: (i // 7, -i))
+        for n, i in enumerate(order):
+            if n % 7 == 0:
+                time.sleep(0.002)
+            on_done(i, out[i])
     return out
 
 
-def _folder_worker(rank, world, port, src, out_dir, q):
+def _folder_worker(rank, world, port, src, out_dir, q, long=False):
     import contextlib
+    import functools
     import io
 
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     from handwritten_ocr_amd import batch, tools
 
     shard.init_from_env(device_backend=False)
-    tools.run_ocr_batch_tokens = _scripted_tokens
+    tools.run_ocr_batch_tokens = functools.partial(_scripted_tokens, long=long)
     tools.decode_tokens = lambda streams: [bytes(t).decode("utf-8") for t in streams]
+    stats = {}
     with contextlib.redirect_stdout(io.StringIO()):
-        outs = batch.transcribe_folder(batch.list_images(src), out_dir, quiet=True)
-    q.put((rank, [o.name for o in outs]))
+        outs = batch.transcribe_folder(batch.list_images(src), out_dir, quiet=True, stats=stats)
+    q.put((rank, ([o.name for o in outs], stats)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _run_folder(world, src, out_dir):
+def _run_folder(world, src, out_dir, long=False, with_stats=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_folder_worker, args=(r, world, port, str(src), str(out_dir), q)) for r in range(world)]
+    procs = [ctx.Process(target=_folder_worker, args=(r, world, port, str(src), str(out_dir), q, long)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=180) for _ in range(world))
+    got = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
-        p.join(180)
+        p.join(300)
         assert p.exitcode == 0
-    return got
+    return got if with_stats else {r: names for r, (names, _) in got.items()}
+
+
+def _same_files(a_dir, b_dir, n_files):
+    import json
+
+    files = sorted(os.listdir(a_dir))
+    assert files == sorted(os.listdir(b_dir)) and len(files) == n_files
+    for fn in files:
+        a, b = (a_dir / fn).read_text(), (b_dir / fn).read_text()
+        if fn.endswith("_trace.json"):  # timestamps differ between runs; everything else must not
+            strip = lambda evs: [{k: v for k, v in e.items() if k not in ("timestamp", "elapsed_seconds")} for e in evs]  # noqa: E731
+            assert strip(json.loads(a)) == strip(json.loads(b)), fn
+        elif fn.endswith("_trace_summary.txt"):
+            assert [l.split("] ", 1)[1] for l in a.splitlines()] == [l.split("] ", 1)[1] for l in b.splitlines()], fn
+        else:
+            assert a == b, fn
 
 
 def test_two_rank_folder_equals_one_rank(tmp_path):
@@ -130,17 +159,36 @@ def test_two_rank_folder_equals_one_rank(tmp_path):
     names = [f"page{i:02d}_transcription.txt" for i in range(5)]
     assert one[0] == names
     assert two[0] == names and two[1] == []          # rank 0 writes every page, rank 1 writes nothing
-    files = sorted(os.listdir(tmp_path / "out1"))
-    assert files == sorted(os.listdir(tmp_path / "out2")) and len(files) == 20
-    for fn in files:
-        a, b = (tmp_path / "out1" / fn).read_text(), (tmp_path / "out2" / fn).read_text()
-        if fn.endswith("_trace.json"):  # timestamps differ between runs; everything else must not
-            strip = lambda evs: [{k: v for k, v in e.items() if k not in ("timestamp", "elapsed_seconds")} for e in evs]
-            assert strip(json.loads(a)) == strip(json.loads(b)), fn
-        elif fn.endswith("_trace_summary.txt"):
-            assert [l.split("] ", 1)[1] for l in a.splitlines()] == [l.split("] ", 1)[1] for l in b.splitlines()], fn
-        else:
-            assert a == b, fn
+    _same_files(tmp_path / "out1", tmp_path / "out2", 20)
+
+
+def test_eight_rank_folder_equals_one_rank_and_rank0_keeps_up(tmp_path):
+    """BASELINE config 3's shape on the CPU: 8 ranks (gloo), 141 pages - ragged shards of 18 and 17 pages, two gather rounds per
+    rank, the second one short or EMPTY on some ranks - with page-length texts.  Files == the 1-rank run's, byte for byte; and rank
+    0's host work per page (detokenise + initial_ocr replay with the native compare / merge + four files) is reported and held to
+    the budget of a full node: 8 GPUs x 15 pages/s leave rank 0 1 / 120 s = 8.3 ms per page."""
+    from PIL import Image
+
+    from handwritten_ocr_amd import batch
+    from handwritten_ocr_amd.synth import make_page
+
+    src = tmp_path / "pages"
+    src.mkdir()
+    n = 141
+    assert (n + 7) // 8 > batch.GATHER_PAGES and n - 7 * ((n + 7) // 8) >= 0
+    for i in range(n):
+        Image.fromarray(make_page(i, 32, 40), "RGB").save(src / f"page{i:03d}.png")
+    one = _run_folder(1, src, tmp_path / "out1", long=True, with_stats=True)
+    eight = _run_folder(8, src, tmp_path / "out8", long=True, with_stats=True)
+    names = [f"page{i:03d}_transcription.txt" for i in range(n)]
+    assert one[0][0] == names and eight[0][0] == names
+    assert all(eight[r][0] == [] for r in range(1, 8))
+    _same_files(tmp_path / "out1", tmp_path / "out8", 4 * n)
+    st = eight[0][1]
+    assert st["pages"] == n and st["gather_rounds"] == 2
+    per_page_ms = 1e3 * st["rank0_host_s"] / n
+    print(f"rank 0 host work: {per_page_ms:.2f} ms per page over {n} pages (8 ranks; budget 8.3 ms)")
+    assert per_page_ms < 8.3, f"rank 0 needs {per_page_ms:.1f} ms of host time per page: it cannot keep up with 8 GPUs at 15 pages/s"
 
 
 def test_ragged_width_gather_single_process_shapes():
@@ -164,10 +212,10 @@ def _failing_folder_worker(rank, world, port, src, out_dir, q):
 
     shard.init_from_env(device_backend=False)
 
-    def reads(images, params=None):
+    def reads(images, params=None, on_done=None):
         if rank == 1:
             raise ValueError("unreadable page on rank 1")
-        return _scripted_tokens(images, params)
+        return _scripted_tokens(images, params, on_done)
 
     tools.run_ocr_batch_tokens = reads
     tools.decode_tokens = lambda streams: [bytes(t).decode("utf-8") for t in streams]

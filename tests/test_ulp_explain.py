@@ -41,9 +41,11 @@ def test_flips_of_the_rounded_intermediates_are_explained_and_garbage_is_not(epi
         assert_close_bf16_explained(out.view(1, -1), want.view(1, -1), ulps=2.0, atol=0.0, what="garbage", mag=None,
                                     candidates=cands, max_frac=1e-3)
     out[11] = want[11].to(torch.bfloat16)
-    out[100:200] = flipped.to(torch.bfloat16)[0]                   # many outliers: not coincidences, whatever they equal
-    with pytest.raises(AssertionError, match="not rounding coincidences"):
-        assert_close_bf16_explained(out.view(1, -1), want.view(1, -1), ulps=2.0, atol=0.0, what="many", mag=None, candidates=cands)
+    # many outliers, each of them a genuine flip of ITS OWN intermediate: explained one by one, but no longer rare
+    xs_up = bf16_neighbours(rbf(v[100:200]))[:, 2]
+    out[100:200] = _epilogue_ref(xs_up.view(1, -1), torch.zeros(100), None, epi).flatten().to(torch.bfloat16)
+    with pytest.raises(AssertionError, match="not rare coincidences"):
+        assert_close_bf16_explained(out.view(1, -1), want.view(1, -1), ulps=0.51, atol=0.0, what="many", mag=None, candidates=cands)
 
 
 def test_gated_candidates_cover_a_gate_and_an_up_flip():

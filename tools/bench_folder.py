@@ -46,13 +46,30 @@ params = {"max_new_tokens": 512, "min_new_tokens": 512}
 with contextlib.redirect_stdout(io.StringIO()):
     tools._load_ocr_model()                                   # weights resident before the clock, as in the reference's 2nd page on
     batch.transcribe_folder(images[: 4 * world], out, params=params, quiet=True)   # warm-up: graphs, LDS attributes
+stats = {}
+model, _ = tools._load_ocr_model()
+if os.environ.get("HWOCR_FOLDER_TRACE"):
+    model.collect_timings = True
+    n_lanes, _ = tools.plan_lanes(3 * n_pages // world, model.max_reads, int(os.environ.get("HWOCR_LANES", "2")))
+    for e in (tools._lanes(n_lanes).engines if n_lanes > 1 else [model]):
+        e.collect_timings = True
 t0 = time.perf_counter()
-outs = batch.transcribe_folder(images, out, params=params, quiet=True)
+outs = batch.transcribe_folder(images, out, params=params, quiet=True, stats=stats)
 dt = time.perf_counter() - t0
 if rank == 0:
     assert len(outs) == len(images) and all(o.exists() for o in outs)
     print(f"{len(images)} pages x 3 strategy reads x 512 tokens through transcribe_folder on {world} rank(s): {dt:.2f} s = "
-          f"{len(images) / dt:.2f} pages/s (4 files per page written; preprocessing on the device: {os.environ['HWOCR_GPU_PREPROCESS']})")
+          f"{len(images) / dt:.2f} pages/s (4 files per page written; preprocessing on the device: {os.environ['HWOCR_GPU_PREPROCESS']}); "
+          f"rank 0 host work {1e3 * stats['rank0_host_s'] / len(images):.2f} ms per page in {stats['gather_rounds']} gather rounds, "
+          f"{1e3 * stats['writer_tail_s']:.0f} ms of it left after the last read stopped")
+    print(f"  read_pages: host preparation {batch.LAST_READ_TIMINGS.get('prepare_s', 0):.2f} s, engine pass {batch.LAST_READ_TIMINGS.get('engine_s', 0):.2f} s")
+    if os.environ.get("HWOCR_FOLDER_TRACE"):
+        engines = tools._lanes(n_lanes).engines if n_lanes > 1 else [model]
+        for li, e in enumerate(engines):
+            tr = getattr(e, "stream_trace", [])
+            adm = [(n, round(ms)) for n, ms in tr if n]
+            dec = [ms for n, ms in tr if not n]
+            print(f"  lane {li}: {len(tr)} trips; admitting trips (reads, ms): {adm}; {len(dec)} decode-only trips, mean {sum(dec) / max(1, len(dec)):.1f} ms")
 if world > 1:
     dist.barrier()
     dist.destroy_process_group()
