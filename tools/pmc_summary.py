@@ -41,7 +41,20 @@ def main():
     fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
     out = {"units": "bytes per launch (mean over the launches of the profiled command)",
            "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 half-count of wide coalesced reads); includes Infinity-Cache hits",
-           "kernels": {}}
+           "kernels": {}, "wide_gemm_forms": {}}
+    # the two forms of the wide GEMM on their own (the family entry above is what bench.py's roofline.traffic reads)
+    global key
+    family = key
+    key = lambda name: ("gemm_wide256w4_kernel (four waves)" if "gemm_wide256w4_kernel" in name else  # noqa: E731
+                        "gemm_wide256_kernel (eight waves)" if family(name) == "gemm_wide256_kernel" else "")
+    fe2, wr2 = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    key = family
+    for k in fe2:
+        if k and fe2[k][0]:
+            n, f, us = fe2[k]
+            wn, w, _ = wr2.get(k, [0, 0.0, 0.0])
+            out["wide_gemm_forms"][k] = {"launches": n, "read_bytes": 2.0 * f / n * 1024.0, "write_bytes": (w / wn * 1024.0) if wn else 0.0,
+                                         "avg_us_under_pmc": us / n}
     for k in sorted(fe, key=lambda k: -fe[k][1]):
         n, f, us = fe[k]
         wn, w, _ = wr.get(k, [0, 0.0, 0.0])
