@@ -257,6 +257,88 @@ def cpu_baseline(cfg, sd_cpu: dict, raw_page: np.ndarray, strategy, n_out: int, 
     return out, {"page": page, "prompt": prompt, "tokens": toks, "logits": torch.stack(logits)}
 
 
+def hf_cpu_reference(cfg, sd_cpu: dict, raw_page: np.ndarray, strategy, ora: dict, n_out: int, reads_per_page: int, t_strings: float) -> dict:
+    """SURVEY.md 8d's wording of the CPU baseline: run_ocr's call sequence (ocr_agent/tools.py:744-769: processor -> generate ->
+    slice) against HF `transformers` itself — the library the reference's CPU path IS — on this host, bf16 as tools.py:707 forces,
+    on the SAME weights, page and prompt as the oracle read of cpu_baseline, which it must reproduce token for token (the oracle is a
+    restatement of these very classes).  Qwen2-VL family only.  The model is built on the meta device and given the engine's weights
+    by reference (load_state_dict(assign=True): no second copy of 2 B parameters); the rotary inv_freq buffers are recomputed in fp32
+    as from_pretrained leaves them.  Per-token times from a StoppingCriteria hook; the steps beyond the measured ones are scaled as
+    in cpu_baseline.  Reported beside cpu_baseline (kind "port"), never a reason to lose the line."""
+    import transformers
+    from PIL import Image
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration, StoppingCriteria, StoppingCriteriaList
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+
+    from handwritten_ocr_amd import preprocess
+    from handwritten_ocr_amd.compat import config
+
+    if cfg.family != "qwen2_vl" or int(cfg.mlp_ratio) != cfg.mlp_ratio:
+        return {"skipped": f"family {cfg.family}: the HF leg is written for the benchmarked Qwen2-VL shape"}
+    hcfg = Qwen2VLConfig(
+        vision_config=dict(depth=cfg.depth, embed_dim=cfg.embed_dim, hidden_size=cfg.hidden, hidden_act="quick_gelu", mlp_ratio=int(cfg.mlp_ratio),
+                           num_heads=cfg.num_heads, in_channels=3, patch_size=cfg.patch_size, spatial_merge_size=cfg.merge,
+                           temporal_patch_size=cfg.tps),
+        text_config=dict(vocab_size=cfg.vocab, hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.layers,
+                         num_attention_heads=cfg.q_heads, num_key_value_heads=cfg.kv_heads, max_position_embeddings=32768,
+                         rms_norm_eps=cfg.eps, tie_word_embeddings=bool(cfg.tie),
+                         rope_parameters={"rope_type": "default", "rope_theta": cfg.rope_theta, "mrope_section": list(cfg.mrope_section)}),
+        image_token_id=cfg.image_token_id, video_token_id=cfg.image_token_id + 1, vision_start_token_id=cfg.vision_start_id,
+        vision_end_token_id=cfg.vision_end_id, tie_word_embeddings=bool(cfg.tie))
+    t0 = time.perf_counter()
+    with torch.device("meta"):
+        model = Qwen2VLForConditionalGeneration(hcfg)
+    res = model.load_state_dict(sd_cpu, strict=False, assign=True)
+    if [k for k in res.missing_keys if k != "lm_head.weight"] or res.unexpected_keys:
+        return {"error": f"state dict does not fit the HF model: missing {res.missing_keys[:3]}, unexpected {res.unexpected_keys[:3]}"}
+    model.tie_weights()
+    vis = model.model.visual.rotary_pos_emb
+    dim = vis.inv_freq.shape[0] * 2
+    vis.inv_freq = 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float) / dim))
+    rot = model.model.language_model.rotary_emb
+    hd = cfg.hidden // cfg.q_heads
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.int64).to(dtype=torch.float) / hd))
+    rot.inv_freq, rot.original_inv_freq = inv, inv.clone()
+    if any(b.is_meta for b in model.buffers()) or any(p_.is_meta for p_ in model.parameters()):
+        return {"error": "a tensor of the HF model is still on the meta device"}
+    model.eval()
+    t_build = time.perf_counter() - t0
+    img = preprocess.apply_strategy(Image.fromarray(raw_page, "RGB"), strategy, quiet=True)
+    t0 = time.perf_counter()
+    proc = Qwen2VLImageProcessorPil(min_pixels=config.OCR_MIN_PIXELS, max_pixels=config.OCR_MAX_PIXELS)
+    px = proc(images=[img], return_tensors="pt")
+    t_img = time.perf_counter() - t0
+    ids = torch.from_numpy(np.asarray(ora["prompt"], np.int64))[None]
+    n = len(ora["tokens"])
+    stamps = []
+
+    class Clock(StoppingCriteria):
+        def __call__(self, input_ids, scores, **kw):
+            stamps.append(time.perf_counter())
+            return torch.zeros(input_ids.shape[0], dtype=torch.bool)
+
+    model.generation_config.eos_token_id, model.generation_config.pad_token_id = list(cfg.eos_ids), cfg.pad_id
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = model.generate(input_ids=ids, pixel_values=px["pixel_values"].to(torch.bfloat16), image_grid_thw=px["image_grid_thw"],
+                             mm_token_type_ids=(ids == cfg.image_token_id).int(), attention_mask=torch.ones_like(ids), do_sample=False,
+                             max_new_tokens=n, min_new_tokens=n, stopping_criteria=StoppingCriteriaList([Clock()]))
+    t_gen = time.perf_counter() - t0
+    toks = out[0, ids.shape[1]:].tolist()
+    t_first = stamps[0] - t0                                   # tower + prefill + the first token
+    t_dec = (stamps[-1] - stamps[0]) / max(1, len(stamps) - 1)  # per decode step
+    t_read = t_img + t_first + (n_out - 1) * t_dec
+    t_page = reads_per_page * t_read + t_strings
+    same = toks == list(ora["tokens"])
+    return {"value": 1.0 / t_page, "unit": "pages/s", "cores": torch.get_num_threads(), "kind": "transformers on the CPU (the library the reference's CPU path runs)",
+            "transformers": transformers.__version__, "seconds_per_page": t_page, "measured_cpu_seconds": t_img + t_gen,
+            "parts_s": {"image_processor": t_img, "tower_prefill_first_token": t_first, "decode_per_token": t_dec, "model_build": t_build},
+            "tokens_equal_to_the_oracle_read": bool(same), "first_difference": None if same else next(i for i, (a, b) in enumerate(zip(toks, ora["tokens"])) if a != b),
+            "sample": f"HF Qwen2VLForConditionalGeneration.generate on this host's cores, bf16, full depth, the engine's own weights, T={ids.shape[1]}, "
+                      f"{n} tokens measured ({n - 1} decode steps timed by a StoppingCriteria hook), the other {n_out - n} steps scaled per token; "
+                      f"x{reads_per_page} serial reads per page + the same compare / merge seconds as cpu_baseline"}
+
+
 def full_depth_parity(eng, ora: dict) -> dict:
     """The engine against the full-depth oracle read of cpu_baseline (same weights, same page, same prompt): teacher-forced logits
     of the first steps, as tests/test_fullwidth_oracle_gpu.py does at depth 2.  Reported, not asserted (the bench never fails on it)."""
@@ -740,6 +822,11 @@ def main() -> None:
             sd_cpu = {k: v.to("cpu") for k, v in engine.normalize_keys(sd).items()}
             del sd
             out["cpu_baseline"], ora = cpu_baseline(cfg, sd_cpu, raws[0], strategies[0], args.new_tokens, args.reads)
+            try:  # the same read through HF transformers itself on the same cores (SURVEY 8d's wording), token for token
+                out["cpu_baseline"]["hf_transformers"] = hf_cpu_reference(cfg, sd_cpu, raws[0], strategies[0], ora, args.new_tokens, args.reads,
+                                                                          out["cpu_baseline"]["parts_s"]["strings"])
+            except Exception as e:
+                out["cpu_baseline"]["hf_transformers"] = {"error": f"{type(e).__name__}: {e}"}
             del sd_cpu
             try:  # the same read through the engine, teacher-forced: full-depth, full-width parity on the bench's own weights
                 out["parity_full_depth_vs_oracle"] = full_depth_parity(eng, ora)
