@@ -415,7 +415,7 @@ def trained_cer(device) -> dict:
 
     gold = os.path.join(ROOT, "tests", "golden")
     out = {"bar": 0.005, "metric": "mean over pages of cer(HF text, engine text)"}
-    for fam, stem in (("qwen2_vl", "trained_qwen2vl"), ("qwen2_5_vl", "trained_qwen25vl")):
+    for fam, stem in (("qwen2_vl", "trained_qwen2vl"), ("qwen2_5_vl", "trained_qwen25vl"), ("paligemma", "trained_paligemma")):
         try:
             with open(os.path.join(gold, stem + ".json"), encoding="utf-8") as f:
                 meta = json.load(f)

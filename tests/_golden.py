@@ -50,7 +50,8 @@ def tiny_ref_config(family="qwen2_vl"):
 
 
 # ------------------------------------------------------------------------------------------------ trained tiny checkpoints
-TRAINED = {"qwen2_vl": "trained_qwen2vl", "qwen2_5_vl": "trained_qwen25vl"}
+TRAINED = {"qwen2_vl": "trained_qwen2vl", "qwen2_5_vl": "trained_qwen25vl", "paligemma": "trained_paligemma"}
+TRAINED_FAMILIES = tuple(TRAINED)
 
 
 def trained_meta(family="qwen2_vl"):

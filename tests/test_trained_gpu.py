@@ -3,7 +3,7 @@ ocr_agent/tools.py:103-118, over the text `generate` returns, tools.py:764-769).
 
 tests/golden/trained_* hold what the real HF classes transcribe — free-running greedy `generate(**inputs, max_new_tokens=128)`
 under the checkpoint's own generation_config, decoded with the checkpoint's tokenizer — from 8 synthetic pages with a briefly
-TRAINED tiny Qwen2-VL / Qwen2.5-VL checkpoint whose greedy choices are decisive (tools/make_goldens.py::make_trained;
+TRAINED tiny Qwen2-VL / Qwen2.5-VL / PaliGemma (bf16) checkpoint whose greedy choices are decisive (tools/make_goldens.py::make_trained;
 tests/test_trained_oracle.py holds the oracle to the same streams on the CPU).  Here the engine reads the same pages FREE-RUNNING
 through every decode path a shipped configuration takes and the text must stay within CER 0.005 of HF's, page set by page set:
 
@@ -24,7 +24,7 @@ from PIL import Image
 
 pytestmark = pytest.mark.gpu
 
-from tests._golden import FAMILIES, mean_cer, trained_dir, trained_meta, trained_page  # noqa: E402
+from tests._golden import TRAINED_FAMILIES as FAMILIES, mean_cer, trained_dir, trained_meta, trained_page  # noqa: E402
 
 CER_BAR = 0.005
 
@@ -81,7 +81,8 @@ def _variants(cfg, reads):
 
 @pytest.mark.parametrize("reads,path", [(8, "gemm_rows16_kernel"), (24, "gemm_stream_kernel<2,"), (252, "rowblocks2")])
 def test_free_running_text_within_the_cer_bar(trained, reads, path):
-    assert path in _variants(trained.cfg, reads), "the case must run the decode path it is named for"
+    if trained.family != "paligemma":   # (Gemma's 256-wide heads take other instances of the same paths: tests/test_decode_variants.py)
+        assert path in _variants(trained.cfg, reads), "the case must run the decode path it is named for"
     idx, pages, prompts = trained.reads(reads)
     streams = trained.eng.generate(pages, prompts, max_new=trained.n)
     m, differing = trained.check(idx, streams, f"{reads} reads in flight")
@@ -140,3 +141,28 @@ def test_the_drop_in_transcribes_within_the_cer_bar(trained, tmp_path, monkeypat
     m5 = mean_cer(trained.hf_texts * 5, many)
     assert m5 <= CER_BAR, f"continuous batching over two lanes: mean CER {m5:.4f}"
     print(f"[trained {trained.family}] drop-in: mean CER {m:.4f} (8 reads), {m5:.4f} (40 reads through 16 slots)")
+
+
+def test_fp8_leg_of_config_4_on_the_trained_paligemma():
+    """BASELINE config 4's fp8 leg has no HF counterpart (parity unpinned: DESIGN.md §5) — but its effect on the OUTPUT can be put
+    next to the accuracy bar: the trained tiny PaliGemma read with E4M3 operands in the wide GEMMs (every Linear of the tower / prefill
+    whose K is a multiple of 128: here the Gemma prefill; decode steps stay bf16) against HF's bf16 text of the same pages.  A stated
+    tolerance of this repo, the same 0.5 % CER; measured on the first run: see the printed line."""
+    from handwritten_ocr_amd import engine, tokenizer
+
+    family = "paligemma"
+    meta, ckpt = trained_meta(family), trained_dir(family)
+    cfg, sd = engine.load_checkpoint_dir(ckpt, device="cuda")
+    eng = engine.ReadEngine(cfg, sd, max_reads=32, ctx=512, vit_batch=12, prefill_batch=16, fp8=True)
+    try:
+        proc = tokenizer.Processor(cfg, tokenizer.HFTokenizer(cfg, ckpt), template_dir=ckpt)
+        prepared = [proc.prepare(Image.fromarray(trained_page(c), "RGB"), meta["prompt"]) for c in meta["cases"]]
+        streams = eng.generate([p for p, _ in prepared] * 3, [q for _, q in prepared] * 3, max_new=meta["max_new_tokens"])
+        texts = [proc.decode(t, skip_special_tokens=True) for t in streams]
+        want = [c["hf_text"] for c in meta["cases"]] * 3
+        m = mean_cer(want, texts)
+        differing = sum(t != c["hf_tokens"] for t, c in zip(streams, meta["cases"] * 3))
+        print(f"[trained paligemma, fp8 wide GEMMs] 24 reads: mean CER {m:.4f} vs HF's bf16 text, {differing}/24 token streams differ")
+        assert m <= CER_BAR, f"fp8 leg: mean CER {m:.4f} vs HF's bf16 text"
+    finally:
+        eng.close()

@@ -15,7 +15,7 @@ from handwritten_ocr_amd import engine, imageproc, tokenizer
 from handwritten_ocr_amd.compat import config
 from oracle import image_ref
 from oracle.qwen2vl_ref import Qwen2VLRef, RefConfig
-from tests._golden import FAMILIES, mean_cer, trained_dir, trained_meta, trained_page
+from tests._golden import TRAINED_FAMILIES as FAMILIES, mean_cer, trained_dir, trained_meta, trained_page
 
 
 def _ref_config(cfg: engine.ModelConfig) -> RefConfig:
@@ -39,6 +39,13 @@ def test_checkpoint_dir_loads_with_its_generation_defaults(family):
     assert all(v.dtype == torch.bfloat16 for v in sd.values())
 
 
+def _siglip_pixel_values(img: Image.Image, size: int) -> torch.Tensor:
+    """HF SiglipImageProcessorPil restated (resize BICUBIC, x 1/255 in float64 cast to float32, (x - 0.5) / 0.5 in float32): [3, S, S]."""
+    arr = np.asarray(img.convert("RGB").resize((size, size), resample=Image.BICUBIC)).transpose(2, 0, 1)
+    x = (arr.astype(np.float64) * (1 / 255)).astype(np.float32)
+    return torch.from_numpy((x - np.float32(0.5)) / np.float32(0.5))
+
+
 @pytest.mark.parametrize("family", FAMILIES)
 def test_host_half_of_run_ocr_gives_hf_prompt_ids_and_text(family):
     """What tools.run_ocr does around the engine, on the checkpoint directory's own files: prompt ids ≡ HF's
@@ -46,12 +53,16 @@ def test_host_half_of_run_ocr_gives_hf_prompt_ids_and_text(family):
     meta = trained_meta(family)
     cfg, _ = engine.load_checkpoint_dir(trained_dir(family), device="cpu")
     cfg.min_pixels, cfg.max_pixels = config.OCR_MIN_PIXELS, config.OCR_MAX_PIXELS   # tools._load_ocr_model (tools.py:700-704)
-    assert (cfg.min_pixels, cfg.max_pixels) == (meta["min_pixels"], meta["max_pixels"])
+    if family != "paligemma":
+        assert (cfg.min_pixels, cfg.max_pixels) == (meta["min_pixels"], meta["max_pixels"])
     proc = tokenizer.Processor(cfg, tokenizer.HFTokenizer(cfg, trained_dir(family)), template_dir=trained_dir(family))
     assert meta["prompt"] == config.OCR_PROMPT
     for case in meta["cases"]:
         page, ids = proc.prepare(Image.fromarray(trained_page(case), "RGB"), meta["prompt"])
-        assert [1, page.shape[0] // cfg.patch_size, page.shape[1] // cfg.patch_size] == case["grid_thw"]
+        if family == "paligemma":
+            assert page.shape[:2] == (meta["image_size"], meta["image_size"])
+        else:
+            assert [1, page.shape[0] // cfg.patch_size, page.shape[1] // cfg.patch_size] == case["grid_thw"]
         assert ids.tolist() == case["input_ids"]
         assert proc.decode(case["hf_tokens"], skip_special_tokens=True) == case["hf_text"]
 
@@ -62,14 +73,27 @@ def test_oracle_free_running_stream_is_hfs(family):
     that stop on EOS stop at the same step, the others run to the 128-token budget), hence CER 0 against HF's text."""
     meta = trained_meta(family)
     cfg, sd = engine.load_checkpoint_dir(trained_dir(family), device="cpu")
-    ref = Qwen2VLRef(_ref_config(cfg), sd)
+    if family == "paligemma":
+        from oracle.paligemma_ref import PaliGemmaRef, PaliRefConfig
+
+        ref = PaliGemmaRef(PaliRefConfig(
+            v_layers=cfg.depth, v_hidden=cfg.embed_dim, v_heads=cfg.num_heads, v_inter=cfg.vit_inter, patch_size=cfg.patch_size,
+            image_size=cfg.image_size, hidden=cfg.hidden, layers=cfg.layers, q_heads=cfg.q_heads, kv_heads=cfg.kv_heads, head_dim=cfg.head_dim,
+            inter=cfg.inter, vocab=cfg.vocab, rope_theta=cfg.rope_theta, image_token_id=cfg.image_token_id, eos_ids=tuple(cfg.eos_ids),
+            pad_id=cfg.pad_id), sd)
+    else:
+        ref = Qwen2VLRef(_ref_config(cfg), sd)
     proc = tokenizer.Processor(cfg, tokenizer.HFTokenizer(cfg, trained_dir(family)), template_dir=trained_dir(family))
     n = meta["max_new_tokens"]
     texts = []
     for case in meta["cases"]:
-        pv, grid = image_ref.pixel_values(Image.fromarray(trained_page(case), "RGB"), meta["min_pixels"], meta["max_pixels"])
-        assert list(grid) == case["grid_thw"]
-        toks, logits = ref.generate(torch.tensor(case["input_ids"]), torch.from_numpy(pv), [grid], max_new=n)
+        img = Image.fromarray(trained_page(case), "RGB")
+        if family == "paligemma":
+            toks, logits = ref.generate(torch.tensor(case["input_ids"]), _siglip_pixel_values(img, meta["image_size"]).to(torch.bfloat16), max_new=n)
+        else:
+            pv, grid = image_ref.pixel_values(img, meta["min_pixels"], meta["max_pixels"])
+            assert list(grid) == case["grid_thw"]
+            toks, logits = ref.generate(torch.tensor(case["input_ids"]), torch.from_numpy(pv), [grid], max_new=n)
         assert toks == case["hf_tokens"], (case["page_seed"], toks[:8], case["hf_tokens"][:8])
         # the fixture's own claim: decisive steps
         top2 = logits.float().topk(2, -1).values

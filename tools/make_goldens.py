@@ -12,7 +12,7 @@ Sources of truth
     seeded random-init Qwen2-VL models — no checkpoint is available offline.
 
 Only data is written: inputs, expected outputs, weights of the random tiny model.  No reference source text.
-Usage: python tools/make_goldens.py [--only text,preprocess,nodes,image,model,model25,paligemma,tokenizer,trained,trained25]
+Usage: python tools/make_goldens.py [--only text,preprocess,nodes,image,model,model25,paligemma,tokenizer,trained,trained25,trainedpg]
 """
 from __future__ import annotations
 
@@ -850,9 +850,122 @@ def make_trained(family: str = "qwen2_vl") -> None:
           f"{len(cases)} streams stop on EOS")
 
 
+def make_trained_paligemma() -> None:
+    """The same for BASELINE config 4's family in bf16: a briefly trained tiny PaliGemma (SigLIP head_dim 72, Gemma head_dim 256)
+    as a checkpoint directory, read by HF's own PaliGemmaProcessor ("<image>" x n + <bos> + prompt + newline, bidirectional prefix)
+    and generate().  Pages are squashed to 56 x 56 by the SigLIP image processor: the paper tint is what survives."""
+    import shutil
+
+    from PIL import Image
+    from safetensors.torch import save_file
+    from transformers import GenerationConfig, PaliGemmaConfig, PaliGemmaForConditionalGeneration, PreTrainedTokenizerFast
+    from transformers.models.paligemma.processing_paligemma import PaliGemmaProcessor
+    from transformers.models.siglip import SiglipImageProcessorPil
+
+    spec, stem = TINYPG, "trained_paligemma"
+    S = spec["vision"]["image_size"]
+    fast = PreTrainedTokenizerFast.from_pretrained(os.path.join(GOLD, "tokenizer_pg_tiny"))
+    pip_ = SiglipImageProcessorPil(size={"height": S, "width": S}, resample=3, do_rescale=True, do_normalize=True,
+                                   image_mean=[0.5] * 3, image_std=[0.5] * 3)
+    pip_.image_seq_length = (S // spec["vision"]["patch_size"]) ** 2
+    pproc = PaliGemmaProcessor(image_processor=pip_, tokenizer=fast)
+    img_id, bos, eos, pad = pproc.image_token_id, fast.bos_token_id, fast.eos_token_id, fast.pad_token_id
+    cfg = PaliGemmaConfig(vision_config=dict(spec["vision"]), text_config=dict(spec["text"]), image_token_id=img_id, projection_dim=256,
+                          hidden_size=256, vocab_size=512, pad_token_id=pad, bos_token_id=bos, eos_token_id=eos)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(int(os.environ.get("HWOCR_TRAINED_THREADS", "1")))
+    torch.use_deterministic_algorithms(True)
+    torch.manual_seed(0)
+    model = PaliGemmaForConditionalGeneration(cfg)
+    prompt = "Extract and return all the text from this handwritten document."
+    texts = _trained_texts(lambda t: len(fast(t, add_special_tokens=False)["input_ids"]))
+    items = []
+    for (seed, (h, w)), tint, text in zip(TRAINED_PAGES, TRAINED_TINTS, texts):
+        img = Image.fromarray(tint_page(make_page(seed, h, w), tint), "RGB")
+        enc = pproc(text="<image>" + prompt, images=img, return_tensors="pt")            # what run_ocr's processor call yields
+        ans = fast(text, add_special_tokens=False)["input_ids"] + [eos]
+        items.append(dict(seed=seed, hw=(h, w), tint=tint, pv=enc["pixel_values"], ids=enc["input_ids"][0].tolist(), ans=ans, text=text))
+    steps = int(os.environ.get("HWOCR_TRAINED_STEPS_PG", "160"))
+    opt = torch.optim.AdamW(model.parameters(), lr=TRAINED_LR, weight_decay=0.0)
+    model.train()
+    for step in range(steps):
+        for g_ in opt.param_groups:
+            g_["lr"] = TRAINED_LR * min(1.0, (step + 1) / 20) * (0.5 * (1 + np.cos(np.pi * step / steps)) * 0.95 + 0.05)
+        opt.zero_grad()
+        total = 0.0
+        for it in items:
+            full = torch.tensor([it["ids"] + it["ans"]])
+            n0 = len(it["ids"])
+            tt = torch.zeros_like(full)
+            tt[0, n0:] = 1                                                   # the prefix is bidirectional, the answer causal
+            out = model(input_ids=full, pixel_values=it["pv"], token_type_ids=tt, attention_mask=torch.ones_like(full),
+                        labels=torch.where(tt == 1, full, torch.full_like(full, -100)))
+            ce = torch.nn.functional.cross_entropy(out.logits[0, n0 - 1:-1].float(), full[0, n0:], reduction="none")
+            wgt = torch.ones_like(ce)
+            wgt[:4] = TRAINED_HEAD_WEIGHT
+            ((ce * wgt).sum() / wgt.sum() / len(items)).backward()
+            total += float(ce.mean().detach())
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        if step % 20 == 0 or step == steps - 1:
+            print(f"  [{stem}] step {step}: loss {total / len(items):.4f}", flush=True)
+    model.eval()
+    out_dir = os.path.join(GOLD, stem)
+    if os.path.isdir(out_dir):
+        shutil.rmtree(out_dir)
+    os.makedirs(out_dir)
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.copy_(prm.to(torch.bfloat16).to(prm.dtype))
+    model.tie_weights()
+    cfg.save_pretrained(out_dir)
+    sd = {k: v.to(torch.bfloat16).contiguous() for k, v in model.state_dict().items() if k != "lm_head.weight"}
+    save_file(sd, os.path.join(out_dir, "model.safetensors"), metadata={"format": "pt"})
+    GenerationConfig(do_sample=False, eos_token_id=eos, pad_token_id=pad, bos_token_id=bos).save_pretrained(out_dir)
+    pproc.tokenizer.save_pretrained(out_dir)
+    pip_.save_pretrained(out_dir)
+    hf = PaliGemmaForConditionalGeneration.from_pretrained(out_dir, dtype=torch.bfloat16).eval()
+    assert hf.model.language_model.rotary_emb.inv_freq.dtype == torch.float32
+    cases, margins_all = [], []
+    for it in items[:TRAINED_EVAL]:
+        input_ids = torch.tensor([it["ids"]])
+        with torch.no_grad():
+            gen = hf.generate(input_ids=input_ids, pixel_values=it["pv"].to(torch.bfloat16), token_type_ids=torch.zeros_like(input_ids),
+                              attention_mask=torch.ones_like(input_ids), max_new_tokens=TRAINED_MAX_NEW, output_logits=True,
+                              return_dict_in_generate=True)
+        new = gen.sequences[0, input_ids.shape[1]:].tolist()
+        logits = torch.stack([l[0] for l in gen.logits]).float()
+        top2 = logits.topk(2, dim=-1).values
+        margins = (top2[:, 0] - top2[:, 1]).tolist()
+        margins_all += margins
+        hf_text = pproc.decode(new, skip_special_tokens=True)
+        cases.append({"page_seed": it["seed"], "page_hw": list(it["hw"]), "page_tint": list(it["tint"]), "input_ids": it["ids"],
+                      "trained_on": it["text"], "hf_tokens": new, "hf_text": hf_text, "margins": [round(m, 4) for m in margins],
+                      "stopped_on_eos": new[-1] in (eos, pad)})
+        print(f"  [{stem}] page {it['seed']}: {len(new)} tokens, min margin {min(margins):.2f}, "
+              f"cer vs trained text {_import_reference_tools().cer(it['text'], hf_text):.4f}")
+    decisive = float(np.mean([m > 1.0 for m in margins_all]))
+    assert decisive >= 0.95, f"greedy decoding is not decisive: margin > 1.0 on {decisive:.3f} of the steps"
+    with open(os.path.join(GOLD, stem + ".json"), "w", encoding="utf-8") as f:
+        json.dump({"source": f"transformers PaliGemmaForConditionalGeneration: {steps} AdamW steps on CPU (1 thread, seeded) on tinted synth.make_page "
+                             "pages -> sentences, saved with save_pretrained, read back with from_pretrained(dtype=bfloat16), inputs from HF's "
+                             "PaliGemmaProcessor(text='<image>' + prompt, images=page), generate(max_new_tokens=128) under the saved "
+                             "generation_config (greedy), decoded with the checkpoint's tokenizer (skip_special_tokens=True)",
+                   "family": "paligemma", "checkpoint_dir": stem, "prompt": prompt, "max_new_tokens": TRAINED_MAX_NEW, "image_size": S,
+                   "eos_token_id": [eos], "pad_token_id": pad, "decisive_fraction_margin_gt_1": round(decisive, 4), "cases": cases},
+                  f, indent=0, ensure_ascii=True)
+    for root, _, files in os.walk(out_dir):
+        for fn in files:
+            os.chmod(os.path.join(root, fn), 0o644)
+    os.chmod(os.path.join(GOLD, stem + ".json"), 0o644)
+    torch.use_deterministic_algorithms(False)
+    torch.set_num_threads(threads)
+    print(f"{stem}: decisive on {decisive:.3f} of {len(margins_all)} steps; {sum(c['stopped_on_eos'] for c in cases)} of {len(cases)} streams stop on EOS")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="text,preprocess,nodes,image,model,model25,paligemma,tokenizer,trained,trained25")
+    ap.add_argument("--only", default="text,preprocess,nodes,image,model,model25,paligemma,tokenizer,trained,trained25,trainedpg")
     only = set(ap.parse_args().only.split(","))
     os.makedirs(GOLD, exist_ok=True)
     if only & {"text", "preprocess"}:
@@ -877,6 +990,8 @@ def main() -> None:
         make_trained("qwen2_vl")
     if "trained25" in only:
         make_trained("qwen2_5_vl")
+    if "trainedpg" in only:
+        make_trained_paligemma()
 
 
 if __name__ == "__main__":
