@@ -11,7 +11,7 @@ import os
 from . import build as _build
 
 SELECT_WS_INTS = 40  # HWOCR_SELECT_WS_INTS
-ABI_VERSION = 13  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
+ABI_VERSION = 14  # == HWOCR_ABI_VERSION of include/hwocr.h; hip() refuses a library that reports another one
 
 P = C.c_void_p
 I = C.c_int
@@ -92,12 +92,12 @@ class Decoder(C.Structure):
 
 
 class Kv(C.Structure):
-    _fields_ = [("k", P), ("vt", P), ("nseq_max", I), ("ctx", I), ("tiled", I)]
+    _fields_ = [("k", P), ("vt", P), ("nseq_max", I), ("ctx", I), ("tiled", I), ("k_scale", P), ("v_scale", P), ("fp8", I)]
 
 
 class DecWs(C.Structure):
     _fields_ = [(n, P) for n in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "arrive", "select_ws", "logits",
-                                  "q8", "q8s")]
+                                  "q8", "q8s", "kt", "vtt")]
 
 
 class Rows16Norm(C.Structure):
@@ -136,6 +136,8 @@ _HIP_SIGS = {
     "hwocr_attn_prefill": ([P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, L, L, F, I, P], I),
     "hwocr_attn_decode": ([P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, P], I),
     "hwocr_attn_decode_qkv": ([P, I, L, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, F, I, I, I, I, P, P], I),
+    "hwocr_attn_decode_qkv_fp8kv": ([P, I, L, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, I, P, P], I),
+    "hwocr_kv_quant_fp8": ([P, P, L, L, L, L, L, P, P, P, P, I, I, I, I, P], I),
     "hwocr_attn_varlen": ([P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, L, F, P], I),
     "hwocr_patchify": ([P, P, P, I, I, I, I, I, I, I, I, P, P], I),
     "hwocr_layernorm": ([P, P, P, P, I, I, I, I, F, P], I),

@@ -738,6 +738,9 @@ struct DecodeArgs {
   // partials itself (nullptr: attn_decode_merge_kernel does, in a launch of its own)
   int* arrive = nullptr;
   int ahead = 1;  // fused QKV finish: first key block requested before the finish (HWOCR_ATTN_DECODE_AHEAD=0: after, for A/B runs)
+  // E4M3 cache (hwocr_kv.fp8; the KV8 kernel instance): K / VT point at the CODES ([seq][Hkv][ctx * 256 bytes], kv8_k / kv8_v order),
+  // one scale per token and kv head [seq][Hkv][ctx]
+  float* k_scale = nullptr; float* v_scale = nullptr;
 };
 
 // partials of query head h of read b, output feature d: all <= 16 (m, l) pairs and output values are loaded up front (indices
@@ -787,10 +790,16 @@ __device__ __forceinline__ void merge_splits(const DecodeArgs& a, int b, int h, 
 // CU; capped to 128 (WPE = 4: two workgroups per CU) hipcc spills 27 dwords and the decode step went from 4.21 to 4.94 ms per token.
 // Keeping the NEXT block's 16 fragment loads in flight while the current block multiplies (double-buffered fragments: 256 VGPRs,
 // 9 dwords of scratch) measured 4.32 against 4.22 ms per token: the loop is not waiting on its own loads.
-template <bool TILED, int WAVES, int DEC_HD, int WPE = (DEC_HD == 256 ? 1 : (WAVES == 8 ? 2 : 3))>
+// KV8 (round 4; head_dim 256, the fp8 configuration): the cache holds E4M3 codes in operand order (common.h kv8_k / kv8_v) + one
+// scale per token: a block is 16 loads of 1 KiB per wave instead of 32, converted to bf16 fragments in registers (exact), the key
+// scale multiplies the score, the value scale the softmax weight before it is packed; the appended token is quantised by the
+// workgroup that owns its block.  Gemma's decode attention is 26 % of config 4's kernel time and streams KV at the HBM rate already
+// (1.13 GB per layer at 5.4 TB/s): halving the bytes is what is left.
+template <bool TILED, int WAVES, int DEC_HD, int WPE = (DEC_HD == 256 ? 1 : (WAVES == 8 ? 2 : 3)), bool KV8 = false>
 __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs a) {
   constexpr int KS = DEC_HD / 32, VD = DEC_HD / 16;  // k-steps of the score product, d-tiles of the PV product
   static_assert(!TILED || DEC_HD == 128, "the fragment-tiled cache layout is defined for head_dim 128");
+  static_assert(!KV8 || (DEC_HD == 256 && WAVES == 4 && !TILED), "the E4M3 cache is defined for 256-wide heads (4 waves = one thread per feature)");
   constexpr int QC = DEC_HD == 256 ? 8 : 16;  // query columns kept for the merge (64 KB static LDS limit): G <= QC
   __shared__ float s_o[WAVES][DEC_HD][QC];
   __shared__ float s_m[WAVES][16];
@@ -801,13 +810,34 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
   const int len = a.lens[b];
   const bf16* Kp = a.K + b * a.k_seq + hk * a.k_head;
   const bf16* Vp = a.VT + b * a.v_seq + hk * a.v_head;
+  // KV8: byte regions of ctx * DEC_HD codes, scales of ctx floats per (read, kv head)
+  const long reg8 = ((long)b * a.Hkv + hk) * (long)a.ctx;
+  const unsigned char* K8 = (const unsigned char*)a.K + reg8 * DEC_HD;
+  const unsigned char* V8 = (const unsigned char*)a.VT + reg8 * DEC_HD;
 
   const int krow = 8 * (c >> 2) + (c & 3);  // key (within the block) of tile-0 row c; tile 1: +4
   const int nblk = (len + 31) >> 5;
-  bf16x8 kf[2][KS], vt[VD];
+  bf16x8 kf[KV8 ? 1 : 2][KV8 ? 1 : KS], vt[KV8 ? 1 : VD];
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 kraw[KV8 ? 2 : 1][KV8 ? KS / 2 : 1], vraw[KV8 ? VD / 2 : 1];  // KV8: a lane's 16 codes of two k-steps / d-tiles per load
+  f32x4 ksc[2], vsc[2];                                                // KV8: scales of this lane's 8 keys (tile t: keys 8 qd + 4 t + e)
   auto load_block = [&](int kb) {
     const int k0 = kb * 32;
-    if constexpr (TILED) {  // one contiguous KiB per fragment, the cache is stored in operand order
+    if constexpr (KV8) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < KS / 2; ++s2)
+          kraw[t][s2] = __builtin_nontemporal_load((const i32x4*)(K8 + ((((long)kb * 2 + t) * (KS / 2) + s2) * 64 + lane) * 16));
+#pragma unroll
+      for (int d2 = 0; d2 < VD / 2; ++d2)
+        vraw[d2] = __builtin_nontemporal_load((const i32x4*)(V8 + (((long)kb * (VD / 2) + d2) * 64 + lane) * 16));
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ksc[t] = *(const f32x4*)(a.k_scale + reg8 + k0 + 8 * qd + 4 * t);
+        vsc[t] = *(const f32x4*)(a.v_scale + reg8 + k0 + 8 * qd + 4 * t);
+      }
+    } else if constexpr (TILED) {  // one contiguous KiB per fragment, the cache is stored in operand order
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -877,7 +907,7 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
       const float x1 = bf2f(s_row[which * DEC_HD + i]), x2 = bf2f(s_row[which * DEC_HD + HALF + i]);
       const bf16 oa = f2bf(rbf(x1 * cs) + rbf(-x2 * sn));
       const bf16 ob = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
-      if (which < a.G) {
+      if (which < a.G || KV8) {   // (KV8: the rotated key is staged behind the query heads and quantised below)
         s_rot[which * DEC_HD + i] = oa;
         s_rot[which * DEC_HD + HALF + i] = ob;
       } else {
@@ -886,7 +916,31 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
         kb[TILED ? kv_tiled_k(slot, HALF + i) : (long)slot * DEC_HD + HALF + i] = ob;
       }
     }
-    if (owner) {
+    if constexpr (KV8) {
+      // the owner quantises the new token: thread d holds feature d of k and of v (256 threads, 256 features); scale = max|x| / 448
+      // over the token's features (1 for an all-zero row), code = e4m3(x * 448 / max|x|), as hwocr_quant_rows_fp8
+      __syncthreads();
+      if (owner) {
+        const float kx = bf2f(s_rot[a.G * DEC_HD + tid]), vx = bf2f(s_row[(a.G + 1) * DEC_HD + tid]);
+        const float km = wave_max(fabsf(kx)), vm = wave_max(fabsf(vx));
+        if (lane == 0) { s_m[w][0] = km; s_m[w][1] = vm; }
+        __syncthreads();
+        const float kmax = fmaxf(fmaxf(s_m[0][0], s_m[1][0]), fmaxf(s_m[2][0], s_m[3][0]));
+        const float vmax = fmaxf(fmaxf(s_m[0][1], s_m[1][1]), fmaxf(s_m[2][1], s_m[3][1]));
+        const float kinv = kmax > 0.f ? 448.0f / kmax : 0.f, vinv = vmax > 0.f ? 448.0f / vmax : 0.f;
+        const int kc = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(kx * kinv, -448.0f), 448.0f), 0.f, 0, false);
+        const int vc = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(vx * vinv, -448.0f), 448.0f), 0.f, 0, false);
+        unsigned char* K8w = (unsigned char*)a.Kw + reg8 * DEC_HD;
+        unsigned char* V8w = (unsigned char*)a.VTw + reg8 * DEC_HD;
+        K8w[kv8_k(slot, tid)] = (unsigned char)(kc & 0xff);
+        V8w[kv8_v(tid, slot)] = (unsigned char)(vc & 0xff);
+        if (tid == 0) {
+          a.k_scale[reg8 + slot] = kmax > 0.f ? kmax / 448.0f : 1.0f;
+          a.v_scale[reg8 + slot] = vmax > 0.f ? vmax / 448.0f : 1.0f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the appended slot is in L2 before any wave reads it back
+      }
+    } else if (owner) {
       for (int d = tid; d < DEC_HD; d += 64 * WAVES)
         a.VTw[b * a.v_seq + hk * a.v_head + (TILED ? kv_tiled_v(d, slot) : (long)d * a.v_row + slot)] = s_row[(a.G + 1) * DEC_HD + d];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the appended slot is in L2 before any wave reads it back
@@ -922,19 +976,42 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
     if (!ahead) load_block(kb);
     ahead = false;
     if (k0 + 32 > len) {  // tail block: keys past the end carry p = 0, keep 0 * x finite
+      if constexpr (KV8) {  // zero the codes (and the value scales) of this lane's keys past the end: bytes nv.. of both 8-byte halves
+        const int nv = max(0, min(8, len - (k0 + 8 * qd)));
+        const unsigned lo = nv >= 4 ? 0xffffffffu : (nv > 0 ? (1u << (8 * nv)) - 1u : 0u);
+        const unsigned hi = nv >= 8 ? 0xffffffffu : (nv > 4 ? (1u << (8 * (nv - 4))) - 1u : 0u);
 #pragma unroll
-      for (int d = 0; d < VD; ++d)
+        for (int d2 = 0; d2 < VD / 2; ++d2) {
+          vraw[d2].x &= (int)lo; vraw[d2].y &= (int)hi; vraw[d2].z &= (int)lo; vraw[d2].w &= (int)hi;
+        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (k0 + 8 * qd + e >= len) vt[d][e] = (bf16)0.0f;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k0 + 8 * qd + 4 * t + e >= len) vsc[t][e] = 0.f;
+      } else {
+#pragma unroll
+        for (int d = 0; d < VD; ++d)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (k0 + 8 * qd + e >= len) vt[d][e] = (bf16)0.0f;
+      }
     }
     // S^T tiles: lane (c, qd) register r of tile t <-> key k0 + 8qd + 4t + r, column = query c
     f32x4 sc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (KV8) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][s], qf[s], sc[t], 0, 0, 0);
+        for (int s2 = 0; s2 < KS / 2; ++s2) {
+          sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e4m3x8_bf16(kraw[t][s2].x, kraw[t][s2].y), qf[2 * s2], sc[t], 0, 0, 0);
+          sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e4m3x8_bf16(kraw[t][s2].z, kraw[t][s2].w), qf[2 * s2 + 1], sc[t], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][s], qf[s], sc[t], 0, 0, 0);
+      }
     }
     float mx = NEG_BIG;
 #pragma unroll
@@ -942,6 +1019,7 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float v = sc[t][e] * a.scale_log2;
+        if constexpr (KV8) v *= ksc[t][e];   // the key's scale: q . (code * scale) = (q . code) * scale
         if (k0 + 8 * qd + 4 * t + e >= len) v = -INFINITY;
         sc[t][e] = v;
         mx = fmaxf(mx, v);
@@ -958,14 +1036,25 @@ __global__ __launch_bounds__(64 * WAVES, WPE) void attn_decode_kernel(DecodeArgs
       for (int e = 0; e < 4; ++e) {
         const float pv = __builtin_amdgcn_exp2f(sc[t][e] - m_new);
         rs += pv;
-        pb[4 * t + e] = f2bf(pv);
+        if constexpr (KV8) pb[4 * t + e] = f2bf(pv * vsc[t][e]);   // the value's scale rides on its softmax weight
+        else pb[4 * t + e] = f2bf(pv);
       }
     l = l * alpha + rs;
     m = m_new;
+    if constexpr (KV8) {
 #pragma unroll
-    for (int d = 0; d < VD; ++d) {
-      o[d] *= alpha;
-      o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[d], pb, o[d], 0, 0, 0);
+      for (int d2 = 0; d2 < VD / 2; ++d2) {
+        o[2 * d2] *= alpha;
+        o[2 * d2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e4m3x8_bf16(vraw[d2].x, vraw[d2].y), pb, o[2 * d2], 0, 0, 0);
+        o[2 * d2 + 1] *= alpha;
+        o[2 * d2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(e4m3x8_bf16(vraw[d2].z, vraw[d2].w), pb, o[2 * d2 + 1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < VD; ++d) {
+        o[d] *= alpha;
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[d], pb, o[d], 0, 0, 0);
+      }
     }
   }
   l += __shfl_xor(l, 16);
@@ -1100,10 +1189,11 @@ extern "C" int hwocr_attn_varlen(const void* Q, const void* K, const void* VT, v
 namespace {
 int launch_attn_decode(const DecodeArgs& a, int nseq, int head_dim, hipStream_t stream) {
   const int Hkv = a.Hkv, nsplit = a.nsplit;
-  HWOCR_PLAN("attn_decode_kernel<%s,%d,%d>%s fused_qkv=%d nseq=%d Hq=%d Hkv=%d nsplit=%d nslab=%d", a.kv_tiled ? "tiled" : "rows",
+  HWOCR_PLAN("attn_decode_kernel<%s,%d,%d>%s fused_qkv=%d nseq=%d Hq=%d Hkv=%d nsplit=%d nslab=%d", a.k_scale ? "e4m3" : a.kv_tiled ? "tiled" : "rows",
              (head_dim == 256 || nsplit > 1) ? 4 : 8, head_dim, nsplit > 1 ? (a.arrive ? "+lastwg" : "+merge") : "", a.slabs != nullptr, nseq, a.Hq, Hkv, nsplit, a.nslab);
   if (head_dim == 256) {  // 4 waves; a single pass when the caller asks for no split
-    hipLaunchKernelGGL((attn_decode_kernel<false, 4, 256>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+    if (a.k_scale) hipLaunchKernelGGL((attn_decode_kernel<false, 4, 256, 1, true>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((attn_decode_kernel<false, 4, 256>), dim3(nsplit, Hkv, nseq), dim3(256), 0, stream, a);
     if (nsplit > 1 && !a.arrive) hipLaunchKernelGGL(attn_decode_merge_kernel<256>, dim3(a.Hq, nseq), dim3(256), 0, stream, a);
     return hwocr_launch_status();
   }
@@ -1161,6 +1251,24 @@ extern "C" int hwocr_attn_decode_qkv(const float* slabs, int nslab, long slab_st
   static const int ahead = HWOCR_DIAG_ENV_INT("HWOCR_ATTN_DECODE_AHEAD", 1);
   a.ahead = ahead;
   return launch_attn_decode(a, nseq, head_dim, stream);
+}
+
+// the fused step over an E4M3 cache (hwocr.h)
+extern "C" int hwocr_attn_decode_qkv_fp8kv(const float* slabs, int nslab, long slab_stride, const void* bias, void* K8, void* VT8,
+                                           float* k_scale, float* v_scale, const int* lens, const int* rope_delta, const void* cos_tab,
+                                           const void* sin_tab, void* out, float* part_o, float* part_ml, int* arrive, int nseq, int Hq,
+                                           int Hkv, int nsplit, float scale, int ctx, int max_pos, int* status, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!attn_decode_args_ok(nseq, Hq, Hkv, nsplit, part_o, part_ml, 0, 0, 0, 0, 0, 256, 0)) return HWOCR_EINVAL;
+  if (!slabs || nslab < 1 || !rope_delta || !cos_tab || !sin_tab || ctx < 32 || (ctx % 32) || max_pos < 1 || !K8 || !VT8 || !k_scale || !v_scale)
+    return HWOCR_EINVAL;
+  DecodeArgs a{nullptr, (const bf16*)K8, (const bf16*)VT8, lens, part_o, part_ml, (bf16*)out, 0, 0, 0, 0, 0, Hq, Hkv, Hq / Hkv, nsplit,
+               scale * 1.4426950408889634f, 0};
+  a.slabs = slabs; a.nslab = nslab; a.slab_stride = slab_stride; a.bias = (const bf16*)bias; a.rope_delta = rope_delta;
+  a.cos_tab = (const bf16*)cos_tab; a.sin_tab = (const bf16*)sin_tab; a.ctx = ctx; a.max_pos = max_pos; a.status = status;
+  a.Kw = (bf16*)K8; a.VTw = (bf16*)VT8; a.arrive = arrive; a.k_scale = k_scale; a.v_scale = v_scale;
+  a.ahead = 1;
+  return launch_attn_decode(a, nseq, 256, stream);
 }
 
 // the kernel instance hwocr_attn_decode runs for these arguments (for the parity tests' coverage check)

@@ -76,6 +76,28 @@ __device__ __forceinline__ long kv_tiled_v(int d, int key) {
 #define HWOCR_DIAG_ENV_FLOAT(name, dflt) (dflt)
 #endif
 
+// E4M3 KV cache of 256-wide heads (hwocr_kv.fp8): BYTE offsets inside one (read, kv head) region of ctx * 256 bytes, 32-key blocks of
+// 8 KiB.  A lane's 16 bytes are its 8 codes of two consecutive k-steps (K) / d-tiles (V^T) of the decode attention's MFMA operands, so
+// a block arrives as 4 + 4 (K: 2 tiles x 4 step pairs) + 8 (V^T: 8 tile pairs) 1-KiB loads per wave:
+//   K  : [block][tile t = 0,1][step pair][lane = 16 qd + c][16 B]   tile row c <-> key 8 (c >> 2) + (c & 3) + 4 t, d = 64 pair + 32 half + 8 qd + e
+//   V^T: [block][d-tile pair][lane = 16 qd + c][16 B]                row d = 32 pair + 16 half + c, keys 8 qd + e
+__device__ __forceinline__ long kv8_k(int key, int d) {
+  const int kl = key & 31, t = (kl >> 2) & 1, c = ((kl >> 3) << 2) | (kl & 3);
+  const int s = d >> 5, qd = (d >> 3) & 3;
+  return (((((long)(key >> 5) * 2 + t) * 4 + (s >> 1)) * 64 + qd * 16 + c) << 4) + (s & 1) * 8 + (d & 7);
+}
+__device__ __forceinline__ long kv8_v(int d, int key) {
+  const int kl = key & 31;
+  return ((((long)(key >> 5) * 8 + (d >> 5)) * 64 + (kl >> 3) * 16 + (d & 15)) << 4) + ((d >> 4) & 1) * 8 + (kl & 7);
+}
+// 8 E4M3 codes (two dwords) -> the bf16 fragment they stand for (every E4M3 value is exactly representable in bf16);
+// v_cvt_scalef32_pk_bf16_fp8 (gfx950): two codes -> two packed bf16 per instruction, scale 1
+__device__ __forceinline__ bf16x8 e4m3x8_bf16(int lo, int hi) {
+  const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+  const bf16x2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+  return __builtin_shufflevector(__builtin_shufflevector(a, b, 0, 1, 2, 3), __builtin_shufflevector(c, d, 0, 1, 2, 3), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // last launch failure of this process (which launcher, which HIP error): read back through hwocr_last_error()
 extern "C" void hwocr_record_error(const char* where, int hip_error, const char* text);
 static inline int hwocr_launch_status_at(const char* where) {

@@ -1024,6 +1024,88 @@ extern "C" int hwocr_quant_rows_fp8(const void* X, void* Q, float* scale, int ro
   return hwocr_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The prefill's fill of an E4M3 KV cache (hwocr_kv.fp8, head_dim 256): bf16 K rows / V^T rows of one prefill call and layer -> codes in
+// the decode attention's operand order (common.h kv8_k / kv8_v) + one scale per token and kv head (scale = max|x| / 448 over the
+// token's 256 features, 1 for an all-zero row; code = e4m3(x * 448 / max|x|): hwocr_quant_rows_fp8's rule).  One 256-thread workgroup per
+// (32-key block, kv head, read).
+struct KvQuantArgs {
+  const bf16* K; const bf16* VT; long k_seq, k_head, v_seq, v_head, v_row;
+  unsigned char* K8; unsigned char* V8; float* ks; float* vs;
+  int Hkv, keys, ctx;
+};
+__global__ __launch_bounds__(256) void kv_quant_fp8_kernel(KvQuantArgs a) {
+  constexpr int HD = 256;
+  const int kb = blockIdx.x, hk = blockIdx.y, j = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __shared__ float s_vmax[32];
+  __shared__ float s_vinv[32];
+  const long reg = ((long)j * a.Hkv + hk) * (long)a.ctx;
+  unsigned char* K8 = a.K8 + reg * HD;
+  unsigned char* V8 = a.V8 + reg * HD;
+  if (tid < 32) s_vmax[tid] = 0.f;
+  __syncthreads();
+  // ---- keys: wave w takes keys 8 w .. 8 w + 7 of the block, a lane 4 consecutive features of a key
+  const bf16* Kp = a.K + j * a.k_seq + hk * a.k_head;
+  for (int i = 0; i < 8; ++i) {
+    const int key = kb * 32 + 8 * w + i;
+    const bf16x4 v = *(const bf16x4*)(Kp + (long)key * HD + 4 * lane);
+    float amax = fmaxf(fmaxf(fabsf(bf2f(v[0])), fabsf(bf2f(v[1]))), fmaxf(fabsf(bf2f(v[2])), fabsf(bf2f(v[3]))));
+    amax = wave_max(amax);
+    const float inv = amax > 0.f ? 448.0f / amax : 0.f;
+    if (lane == 0) a.ks[reg + key] = amax > 0.f ? amax / 448.0f : 1.0f;
+    float f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = fminf(fmaxf(bf2f(v[e]) * inv, -448.0f), 448.0f);
+    int code = 0;
+    code = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], code, false);
+    code = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], code, true);
+    *(int*)(K8 + kv8_k(key, 4 * lane)) = code;   // features 4 lane .. 4 lane + 3 are 4 consecutive bytes of one 8-byte group
+  }
+  // ---- values: thread d holds row d of V^T, the block's 32 keys; per-key maxima through LDS
+  const bf16* Vp = a.VT + j * a.v_seq + hk * a.v_head + (long)tid * a.v_row + kb * 32;
+  bf16x8 vv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) vv[g] = *(const bf16x8*)(Vp + 8 * g);
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)   // non-negative floats order like their bit patterns
+      atomicMax((int*)&s_vmax[8 * g + e], __float_as_int(fabsf(bf2f(vv[g][e]))));
+  __syncthreads();
+  if (tid < 32) {
+    const float amax = s_vmax[tid];
+    s_vinv[tid] = amax > 0.f ? 448.0f / amax : 0.f;
+    a.vs[reg + kb * 32 + tid] = amax > 0.f ? amax / 448.0f : 1.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {   // keys 8 g .. 8 g + 7 of row tid: the 8 bytes at kv8_v(tid, 32 kb + 8 g)
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(bf2f(vv[g][e]) * s_vinv[8 * g + e], -448.0f), 448.0f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    *(int2*)(V8 + kv8_v(tid, kb * 32 + 8 * g)) = make_int2(lo, hi);
+  }
+}
+
+extern "C" int hwocr_kv_quant_fp8(const void* K, const void* VT, long k_seq, long k_head, long v_seq, long v_head, long v_row, void* K8,
+                                  void* VT8, float* k_scale, float* v_scale, int nseq, int Hkv, int keys, int ctx, hipStream_t stream) {
+  (void)hipGetLastError();
+  if (!K || !VT || !K8 || !VT8 || !k_scale || !v_scale || nseq <= 0 || Hkv <= 0 || keys <= 0 || (keys % 32) || keys > ctx || (ctx % 32) ||
+      (v_row % 8) || v_row < keys || (k_seq % 4) || (k_head % 4) || (v_seq % 8) || (v_head % 8))
+    return HWOCR_EINVAL;
+  KvQuantArgs a{(const bf16*)K, (const bf16*)VT, k_seq, k_head, v_seq, v_head, v_row, (unsigned char*)K8, (unsigned char*)VT8, k_scale,
+                v_scale, Hkv, keys, ctx};
+  HWOCR_PLAN("kv_quant_fp8_kernel nseq=%d Hkv=%d keys=%d ctx=%d", nseq, Hkv, keys, ctx);
+  hipLaunchKernelGGL(kv_quant_fp8_kernel, dim3(keys / 32, Hkv, nseq), dim3(256), 0, stream, a);
+  return hwocr_launch_status();
+}
+
 // the instance of a one-wave-per-row kernel whose chunk count fits the row: 1, 2, 3, 4 or 8 chunks of 8 elements per lane
 struct LaunchLayerNorm {
   template <int NC> static void go(int grid, hipStream_t st, const LayerNormArgs& a) {

@@ -257,6 +257,9 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
       seq0 + nseq > kv->nseq_max || nseq > 128 || (m->head_dim != 128 && m->head_dim != 256) ||
       (m->head_dim != 128 && kv->tiled))
     return HWOCR_EINVAL;
+  // E4M3 cache (hwocr_kv.fp8): this call's K / V^T stay bf16 in the workspace (ws->kt / ws->vtt: the prefill attention reads them),
+  // then hwocr_kv_quant_fp8 fills the cache
+  if (kv->fp8 && (m->head_dim != 256 || kv->tiled || !kv->k_scale || !kv->v_scale || !ws->kt || !ws->vtt || (kv->ctx % 32))) return HWOCR_EINVAL;
   const int HD = m->head_dim, G = m->gemma;
   const int rows = nseq * rows_per_seq, Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD;
   const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
@@ -264,8 +267,11 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
   CHECK(hwocr_embed_splice(ids, img_row, m->embed, img_embeds, ws->h, rows, Hd, G ? m->embed_scale : 1.0f, st));
   for (int l = 0; l < m->layers; ++l) {
     const hwocr_dec_layer& L = m->L[l];
-    bf16* Kc = B(kv->k) + l * k_layer + seq0 * k_seq;
-    bf16* Vc = B(kv->vt) + l * k_layer + seq0 * k_seq;
+    bf16* Kc = kv->fp8 ? B(ws->kt) : B(kv->k) + l * k_layer + seq0 * k_seq;
+    bf16* Vc = kv->fp8 ? B(ws->vtt) : B(kv->vt) + l * k_layer + seq0 * k_seq;
+    // strides of where this layer's K / V^T live while the prompt is attended over: the cache, or the per-call bf16 scratch
+    const long a_head = kv->fp8 ? (long)rows_per_seq * HD : k_head, a_seq = kv->fp8 ? (long)m->Hkv * a_head : k_seq;
+    const int a_ctx = kv->fp8 ? rows_per_seq : kv->ctx;
     const bool q1 = runs_fp8(L.qkv8, ws->q8, ws->q8s, Hd), q2 = runs_fp8(L.gate_up8, ws->q8, ws->q8s, Hd);
     if (q1)
       CHECK(hwocr_rmsnorm_fp8(ws->h, Hd, L.in_norm_w, ws->q8, ws->q8s, Hd, rows, Hd, m->eps, G, st));
@@ -275,12 +281,18 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
     CHECK(wide(ws->hn, L.qkv_w, L.qkv8, ws->q8, ws->q8s, L.qkv_b, nullptr, ws->qkv, rows, QW, Hd, QW, 0, HWOCR_EPI_LINEAR,
                st, q1));
     CHECK(hwocr_mrope_kv_prefill(ws->qkv, ws->q, Kc, Vc, pos3, m->rope_cos, m->rope_sin, rows, rows_per_seq, m->Hq,
-                                 m->Hkv, m->sec0, m->sec1, k_seq, k_head, k_seq, k_head, kv->ctx, HD, kv->tiled, st));
+                                 m->Hkv, m->sec0, m->sec1, a_seq, a_head, a_seq, a_head, a_ctx, HD, kv->tiled, st));
     // Gemma (PaliGemma): the whole prompt is a bidirectional prefix; Qwen: causal
     CHECK(hwocr_attn_prefill(ws->q, Kc, Vc, ws->attn, seq_lens, nseq, m->Hq, m->Hq / m->Hkv, HD, max_len, G ? 0 : 1,
                              (long)rows_per_seq * m->Hq * HD, HD, (long)m->Hq * HD,  // Q [row][Hq][128]
-                             k_seq, k_head, HD, k_seq, k_head, kv->ctx,
+                             a_seq, a_head, HD, a_seq, a_head, a_ctx,
                              (long)rows_per_seq * m->Hq * HD, (long)m->Hq * HD, scale, kv->tiled, st));
+    if (kv->fp8) {  // the cache's share of this layer: codes + one scale per token, for every position of the padded prompt
+      const long s_layer = (long)kv->nseq_max * m->Hkv * kv->ctx, s_seq = (long)m->Hkv * kv->ctx;
+      CHECK(hwocr_kv_quant_fp8(Kc, Vc, a_seq, a_head, a_seq, a_head, a_ctx, (unsigned char*)kv->k + l * k_layer + seq0 * k_seq,
+                               (unsigned char*)kv->vt + l * k_layer + seq0 * k_seq, kv->k_scale + l * s_layer + seq0 * s_seq,
+                               kv->v_scale + l * s_layer + seq0 * s_seq, nseq, m->Hkv, rows_per_seq, kv->ctx, st));
+    }
     CHECK(wide(ws->attn, L.o_w, L.o8, ws->q8, ws->q8s, nullptr, ws->h, ws->h, rows, Hd, m->Hq * HD, Hd, Hd,
                HWOCR_EPI_RESIDUAL, st));
     if (q2)
@@ -314,6 +326,24 @@ extern "C" int hwocr_prefill(const hwocr_decoder* m, const hwocr_dec_ws* ws, con
   return HWOCR_OK;
 }
 
+
+// this layer's attention of a decode step (fused q / k / v finish) over the bf16 cache or, hwocr_kv.fp8, over the E4M3 one
+static int decode_attention(const hwocr_decoder* m, const hwocr_dec_ws* ws, const hwocr_kv* kv, const hwocr_gen_state* gs, int l,
+                            const float* slabs, int nslab, const void* bias, int* arrive, int nseq, int attn_splits, hipStream_t st) {
+  const int HD = m->head_dim, QW = (m->Hq + 2 * m->Hkv) * HD;
+  const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
+  const float scale = 1.0f / sqrtf((float)HD);
+  if (kv->fp8) {
+    const long s_layer = (long)kv->nseq_max * m->Hkv * kv->ctx;
+    return hwocr_attn_decode_qkv_fp8kv(slabs, nslab, (long)nseq * QW, bias, (unsigned char*)kv->k + l * k_layer, (unsigned char*)kv->vt + l * k_layer,
+                                       kv->k_scale + l * s_layer, kv->v_scale + l * s_layer, gs->lens, gs->rope_delta, m->rope_cos, m->rope_sin,
+                                       ws->attn, ws->part_o, ws->part_ml, arrive, nseq, m->Hq, m->Hkv, attn_splits, scale, kv->ctx, m->max_pos,
+                                       gs->status, st);
+  }
+  return hwocr_attn_decode_qkv(slabs, nslab, (long)nseq * QW, bias, B(kv->k) + l * k_layer, B(kv->vt) + l * k_layer, gs->lens, gs->rope_delta,
+                               m->rope_cos, m->rope_sin, ws->attn, ws->part_o, ws->part_ml, arrive, nseq, m->Hq, m->Hkv, attn_splits, k_seq,
+                               k_head, k_seq, k_head, kv->ctx, scale, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st);
+}
 
 // split-K of the three slab-producing GEMMs of a decode step (qkv, o, down) at `nseq` reads in flight
 static void decode_splits(const hwocr_decoder* m, int nseq, int& s_qkv, int& s_o, int& s_d) {
@@ -386,6 +416,7 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
   if (!m || !ws || !kv || !gs || nseq <= 0 || nseq > 256 || nseq > kv->nseq_max || attn_splits < 1 || attn_splits > 16 ||
       m->max_pos < 1 || (m->head_dim != 128 && m->head_dim != 256) || (m->head_dim != 128 && kv->tiled))
     return HWOCR_EINVAL;
+  if (kv->fp8 && (m->head_dim != 256 || kv->tiled || !kv->k_scale || !kv->v_scale || (kv->ctx % 32))) return HWOCR_EINVAL;
   const int HD = m->head_dim, G = m->gemma;
   const int Hd = m->hidden, QW = (m->Hq + 2 * m->Hkv) * HD, OW = m->Hq * HD;
   const long k_head = (long)kv->ctx * HD, k_seq = (long)m->Hkv * k_head, k_layer = (long)kv->nseq_max * k_seq;
@@ -410,9 +441,7 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
       // the next layer's norm prologue still reads): (sd16 * hidden + QW) * nseq floats in all - hwocr_decode_slab_floats
       float* qkv_slab = ws->slabs + (long)sd16 * nseq * Hd;
       CHECK(hwocr_gemm_rows16(nullptr, 0, L.qkv_wt, qkv_slab, QW, nseq, QW, Hd, HWOCR_EPI_PARTIAL, 1, &n1, st));
-      CHECK(hwocr_attn_decode_qkv(qkv_slab, 1, (long)nseq * QW, L.qkv_b, Kc, Vc, gs->lens, gs->rope_delta, m->rope_cos,
-                                  m->rope_sin, ws->attn, ws->part_o, ws->part_ml, decode_lastwg() ? ws->arrive : nullptr, nseq, m->Hq, m->Hkv, attn_splits, k_seq, k_head,
-                                  k_seq, k_head, kv->ctx, scale, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
+      CHECK(decode_attention(m, ws, kv, gs, l, qkv_slab, 1, L.qkv_b, decode_lastwg() ? ws->arrive : nullptr, nseq, attn_splits, st));
       CHECK(hwocr_gemm_rows16(ws->attn, OW, L.o_wt, hbuf[cur], Hd, nseq, Hd, OW, HWOCR_EPI_RESIDUAL, 1, nullptr, st));
       hwocr_rows16_norm n2{hbuf[cur], nullptr, Hd, nullptr, 0, 0, 0, L.post_norm_w, m->eps, G};
       CHECK(hwocr_gemm_rows16(nullptr, 0, L.gate_up_wt, ws->act, m->inter, nseq, 2 * m->inter, Hd, G ? HWOCR_EPI_GEGLU : HWOCR_EPI_SWIGLU, 1,
@@ -437,15 +466,14 @@ extern "C" int hwocr_decode_step(const hwocr_decoder* m, const hwocr_dec_ws* ws,
     // HWOCR_DECODE_FUSE_QKV=0: the two separate launches, for A/B runs)
     static const bool fuse_qkv = HWOCR_DIAG_ENV_INT("HWOCR_DECODE_FUSE_QKV", 1) != 0;
     if (!fuse_qkv) {
+      if (kv->fp8) return HWOCR_EINVAL;  // (the E4M3 cache exists in the fused form only)
       CHECK(hwocr_decode_qkv_finish(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, ws->q, Kc, Vc, gs->lens, gs->rope_delta,
                                     m->rope_cos, m->rope_sin, nseq, m->Hq, m->Hkv, k_seq, k_head, k_seq, k_head,
                                     kv->ctx, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
       CHECK(hwocr_attn_decode(ws->q, Kc, Vc, gs->lens, ws->attn, ws->part_o, ws->part_ml, decode_lastwg() ? ws->arrive : nullptr, nseq, m->Hq, m->Hkv,
                               attn_splits, k_seq, k_head, k_seq, k_head, kv->ctx, scale, HD, kv->tiled, st));
     } else
-    CHECK(hwocr_attn_decode_qkv(ws->slabs, s_qkv, (long)nseq * QW, L.qkv_b, Kc, Vc, gs->lens, gs->rope_delta, m->rope_cos,
-                                m->rope_sin, ws->attn, ws->part_o, ws->part_ml, decode_lastwg() ? ws->arrive : nullptr, nseq, m->Hq, m->Hkv, attn_splits, k_seq, k_head,
-                                k_seq, k_head, kv->ctx, scale, HD, kv->tiled, kv->ctx, m->max_pos, gs->status, st));
+    CHECK(decode_attention(m, ws, kv, gs, l, ws->slabs, s_qkv, L.qkv_b, decode_lastwg() ? ws->arrive : nullptr, nseq, attn_splits, st));
     CHECK(decode_gemm(ws->attn, L.o_w, L.o_wt, L.o8t, L.o8.scale, ws->slabs, nseq, Hd, OW, Hd, HWOCR_EPI_PARTIAL, s_o, st));
     CHECK(hwocr_add_rmsnorm(ws->slabs, s_o, (long)nseq * Hd, Hd, nullptr, ws->h, Hd, L.post_norm_w, ws->hn, Hd,
                             nullptr, nseq, Hd, m->eps, G, st));

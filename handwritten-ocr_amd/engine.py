@@ -417,6 +417,8 @@ def decode_plan(cfg: ModelConfig, reads: int, fp8: bool = False, attn_splits: in
     dec, one, _keep = _placeholder_decoder(cfg, fp8)
     ws = _lib.DecWs(**{k: one for k in ("h", "hn", "qkv", "q", "attn", "act", "slabs", "part_o", "part_ml", "arrive", "select_ws", "logits")})
     kv = _lib.Kv(k=one, vt=one, nseq_max=max(reads, 1), ctx=2048, tiled=1 if cfg.head_dim == 128 else 0)
+    if fp8 and cfg.head_dim == 256:   # the fp8 engine of a 256-wide-head model keeps an E4M3 KV cache (ReadEngine.fp8_kv)
+        kv.k_scale, kv.v_scale, kv.fp8 = one, one, 1
     eos = (C.c_int * 4)(0, 0, 0, 0)
     gs = _lib.GenState(cur_ids=one, lens=one, n_gen=one, finished=one, out_tokens=one, rope_delta=one, max_new=8, min_new=0, n_eos=1,
                        pad_id=0, eos=eos, seen=None, seen_ld=0, rep_penalty=1.0, status=one, do_sample=0, temperature=1.0, top_k=0,
@@ -502,6 +504,9 @@ def wide_plan(cfg: ModelConfig, hw: tuple[int, int], pages: int, reads: int, pro
         dws.q8, dws.q8s = one, one
     Tp = _ceil(prompt_len, 64)
     kv = _lib.Kv(k=one, vt=one, nseq_max=max(reads, 1), ctx=_ceil(Tp + 64, 64), tiled=1 if HD == 128 else 0)
+    if fp8 and HD == 256:   # the E4M3 KV cache of the fp8 engine (ReadEngine.fp8_kv): the prefill fills it from a bf16 scratch
+        kv.k_scale, kv.v_scale, kv.fp8 = one, one, 1
+        dws.kt, dws.vtt = one, one
     eos = (C.c_int * 4)(0, 0, 0, 0)
     gs = _lib.GenState(cur_ids=one, lens=one, n_gen=one, finished=one, out_tokens=one, rope_delta=one, max_new=8, min_new=0,
                        n_eos=1, pad_id=0, eos=eos, seen=None, seen_ld=0, rep_penalty=1.0, status=one, do_sample=0,
@@ -564,7 +569,7 @@ class ReadEngine:
 
     def __init__(self, cfg: ModelConfig, state_dict: dict, max_reads: int = 96, ctx: int = 2048, device: str | None = None,
                  vit_batch: int = 8, prefill_batch: int = 16, attn_splits: int = 0, fp8: bool = False,
-                 fp8_decode: bool | None = None):
+                 fp8_decode: bool | None = None, fp8_kv: bool | None = None):
         """device: None = the process's current device (one process per GPU: shard.init_from_env has already made
         LOCAL_RANK's device current).  fp8: run the wide GEMMs of the vision tower and of the decoder prefill (K a multiple
         of 128) on E4M3 copies of the weights with per-token activation scales (BASELINE config 4); norms and attention stay
@@ -588,6 +593,9 @@ class ReadEngine:
         self.prefill_batch = prefill_batch
         self.attn_splits = attn_splits or int(os.environ.get("HWOCR_ATTN_SPLITS", "0"))  # 0: pick_attn_splits
         self.fp8 = bool(fp8)
+        # E4M3 KV cache (with fp8, 256-wide heads = PaliGemma / Gemma; default on, HWOCR_FP8_KV=0 or fp8_kv=False: bf16 cache): one byte
+        # per cached element + one scale per token and kv head; the decode attention of config 4 streams half the bytes
+        self.fp8_kv = self.fp8 and cfg.head_dim == 256 and (os.environ.get("HWOCR_FP8_KV", "1") not in ("", "0") if fp8_kv is None else bool(fp8_kv))
         self.fp8_decode = self.fp8 and (os.environ.get("HWOCR_FP8_DECODE", "0") not in ("", "0") if fp8_decode is None else bool(fp8_decode))
         self.collect_timings = False
         self.timings = {}
@@ -837,11 +845,19 @@ class ReadEngine:
         bf = torch.bfloat16
         HD = c.head_dim
         kv_elems = c.layers * R * c.kv_heads * self.ctx * HD
-        self.k_cache = torch.zeros(kv_elems, dtype=bf, device=dev)
-        self.vt_cache = torch.zeros(kv_elems, dtype=bf, device=dev)
-        # fragment-tiled cache for head_dim 128; Gemma's 256-wide heads use the row layout
-        self.kv = _lib.Kv(k=_lib.ptr(self.k_cache), vt=_lib.ptr(self.vt_cache), nseq_max=R, ctx=self.ctx,
-                          tiled=1 if HD == 128 else 0)
+        if self.fp8_kv:   # E4M3 codes in operand order (csrc/common.h kv8_k / kv8_v) + scales [layer][read][kv head][ctx]
+            self.k_cache = torch.zeros(kv_elems, dtype=torch.uint8, device=dev)
+            self.vt_cache = torch.zeros(kv_elems, dtype=torch.uint8, device=dev)
+            self.k_scale = torch.ones(kv_elems // HD, dtype=torch.float32, device=dev)
+            self.v_scale = torch.ones(kv_elems // HD, dtype=torch.float32, device=dev)
+            self.kv = _lib.Kv(k=_lib.ptr(self.k_cache), vt=_lib.ptr(self.vt_cache), nseq_max=R, ctx=self.ctx, tiled=0,
+                              k_scale=_lib.ptr(self.k_scale), v_scale=_lib.ptr(self.v_scale), fp8=1)
+        else:
+            self.k_cache = torch.zeros(kv_elems, dtype=bf, device=dev)
+            self.vt_cache = torch.zeros(kv_elems, dtype=bf, device=dev)
+            # fragment-tiled cache for head_dim 128; Gemma's 256-wide heads use the row layout
+            self.kv = _lib.Kv(k=_lib.ptr(self.k_cache), vt=_lib.ptr(self.vt_cache), nseq_max=R, ctx=self.ctx,
+                              tiled=1 if HD == 128 else 0)
         i32 = dict(dtype=torch.int32, device=dev)
         self.cur_ids = torch.zeros(R, **i32)
         self.lens = torch.zeros(R, **i32)
@@ -880,6 +896,9 @@ class ReadEngine:
             if self.fp8:  # E4M3 staging of one prefill GEMM input + its row scales
                 self._bufs["q8"] = torch.empty(rows * max(c.hidden, c.q_heads * HD, c.inter), dtype=torch.uint8, device=dev)
                 self._bufs["q8s"] = torch.empty(rows, dtype=torch.float32, device=dev)
+            if self.fp8_kv:  # one prefill call's K / V^T of one layer in bf16 (the prompt is attended over these; the cache gets codes)
+                self._bufs["kt"] = torch.zeros(rows * c.kv_heads * HD + 64 * HD, dtype=bf, device=dev)
+                self._bufs["vtt"] = torch.zeros(rows * c.kv_heads * HD + 64 * HD, dtype=bf, device=dev)
             for n in {1, min(16, R), min(17, R), R}:   # the library's own statement of what a step writes there (hwocr.h)
                 need = int(self.lib.hwocr_decode_slab_floats(C.byref(self.dec), n))
                 if need < 0 or need > slab_elems:

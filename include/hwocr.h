@@ -38,7 +38,7 @@ typedef struct ihipStream_t* hwocr_stream_t; /* == hipStream_t */
 #define HWOCR_EPI_GELU_TANH 6 /* nn.GELU(approximate="tanh"): SigLIP MLP (HF siglip/modeling_siglip.py:310-322) */
 #define HWOCR_EPI_GEGLU 7     /* SWIGLU's interleaved tile pairs with the tanh GELU as gate: Gemma MLP (HF gemma/modeling_gemma.py:84-97) */
 
-#define HWOCR_ABI_VERSION 13 /* bumped whenever a signature or struct layout below changes */
+#define HWOCR_ABI_VERSION 14 /* bumped whenever a signature or struct layout below changes */
 int hwocr_abi_version(void);
 /* text of the most recent launch failure in this process ("" if none): launcher name + HIP error */
 const char* hwocr_last_error(void);
@@ -144,6 +144,20 @@ int hwocr_attn_decode_qkv(const float* slabs, int nslab, long slab_stride, const
                           float* part_o, float* part_ml, int* arrive, int nseq, int Hq, int Hkv, int nsplit, long k_seq, long k_head,
                           long v_seq, long v_head, long v_row, float scale, int head_dim, int kv_tiled, int ctx, int max_pos,
                           int* status, hwocr_stream_t stream);
+
+/* hwocr_attn_decode_qkv over an E4M3 cache (hwocr_kv.fp8; head_dim 256, row-free operand order): the appended token is quantised
+ * (its own scale), keys / values are converted to bf16 in registers - exact: E4M3 is a subset of bf16 - the key scale multiplies the
+ * score, the value scale the softmax weight.  k_scale / v_scale: this layer's [seq][Hkv][ctx]. */
+int hwocr_attn_decode_qkv_fp8kv(const float* slabs, int nslab, long slab_stride, const void* bias, void* K8, void* VT8,
+                                float* k_scale, float* v_scale, const int* lens, const int* rope_delta, const void* cos_tab,
+                                const void* sin_tab, void* out, float* part_o, float* part_ml, int* arrive, int nseq, int Hq, int Hkv,
+                                int nsplit, float scale, int ctx, int max_pos, int* status, hwocr_stream_t stream);
+
+/* bf16 K [nseq][Hkv] rows of 256 (strides k_seq / k_head, in elements) and V^T [nseq][Hkv][256][...] (v_seq / v_head / v_row) of
+ * `keys` positions per read (a multiple of 32) -> the E4M3 cache regions K8 / VT8 [nseq][Hkv][ctx * 256 bytes] + scales
+ * [nseq][Hkv][ctx] (hwocr_kv.fp8 layout).  The prefill's cache fill. */
+int hwocr_kv_quant_fp8(const void* K, const void* VT, long k_seq, long k_head, long v_seq, long v_head, long v_row, void* K8, void* VT8,
+                       float* k_scale, float* v_scale, int nseq, int Hkv, int keys, int ctx, hwocr_stream_t stream);
 
 /* as hwocr_gemm_skinny_variant, for hwocr_attn_decode */
 int hwocr_attn_decode_variant(int nsplit, int head_dim, int kv_tiled, char* name, int name_len);
@@ -309,8 +323,14 @@ typedef struct {
 } hwocr_decoder;
 
 typedef struct { /* KV cache: K [layer][seq][Hkv][ctx][128], VT [layer][seq][Hkv][128][ctx]; tiled != 0: every
-                  * (seq, kv head) region is stored in the fragment-tiled order of csrc/common.h (kv_tiled_k/_v) */
+                  * (seq, kv head) region is stored in the fragment-tiled order of csrc/common.h (kv_tiled_k/_v).
+                  * fp8 != 0 (head_dim 256 only, the fp8 configuration: BASELINE config 4): k / vt hold E4M3 CODES, one byte per
+                  * element, every (seq, kv head) region of ctx * 256 bytes in the operand order of csrc/common.h (kv8_k / kv8_v:
+                  * 32-key blocks, a lane's 16 bytes = its 8 codes of two consecutive k-steps / d-tiles), with ONE fp32 scale per
+                  * cached token and kv head: k_scale, v_scale [layer][seq][Hkv][ctx] (value = code * scale; scale = max|x| / 448
+                  * over the token's 256 features, as hwocr_quant_rows_fp8).  Half the bytes a decode step streams. */
   void* k; void* vt; int nseq_max, ctx, tiled;
+  float *k_scale, *v_scale; int fp8;
 } hwocr_kv;
 
 typedef struct {
@@ -324,6 +344,8 @@ typedef struct {
   void *logits;                           /* bf16 [nseq][vocab] */
   void* q8;                               /* E4M3 staging of one prefill GEMM input, rows * max(hidden, Hq*head_dim, inter) bytes, or NULL */
   float* q8s;                             /* its row scales [rows] */
+  void *kt, *vtt;                         /* hwocr_kv.fp8 only: bf16 K [nseq][Hkv][rows_per_seq][256] and V^T [nseq][Hkv][256][rows_per_seq] of ONE
+                                           * prefill call and layer (the prefill attention reads them; hwocr_kv_quant_fp8 then fills the cache) */
 } hwocr_dec_ws;
 
 typedef struct {

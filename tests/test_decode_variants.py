@@ -44,6 +44,21 @@ def _attn_plan_variant(nsplit, hd, tiled, arrive):
     return buf.value.decode().split("\n")[0].split(" ")[0]
 
 
+def _attn_plan_variant_e4m3(nsplit, arrive):
+    """... of hwocr_attn_decode_qkv_fp8kv (the fused step over the E4M3 KV cache of 256-wide heads)."""
+    lib = _lib.hip()
+    one = C.c_void_p(64)
+    assert lib.hwocr_plan_begin() == 0
+    rc = lib.hwocr_attn_decode_qkv_fp8kv(one, 1, 8, None, one, one, one, one, one, one, one, one, one, one, one, one if arrive else None, 4, 8,
+                                         1, nsplit, 1.0, 512, 1024, one, None)
+    need = C.c_int()
+    lib.hwocr_plan_end(None, 0, C.byref(need))
+    buf = C.create_string_buffer(need.value)
+    lib.hwocr_plan_end(buf, len(buf), C.byref(need))
+    assert rc == 0
+    return buf.value.decode().split("\n")[0].split(" ")[0]
+
+
 def _rows16_variant(B, N, K, epi, splitk, norm, nslab, gemma):
     """The instance + path class hwocr_gemm_rows16 notes for a call (plan recording: nothing is launched)."""
     lib = _lib.hip()
@@ -104,10 +119,15 @@ def test_every_dispatched_decode_kernel_has_an_oracle_case(preset):
 def test_every_dispatched_e4m3_decode_kernel_has_an_oracle_case(preset):
     """The same for engines built with fp8=True (E4M3 decode weights, hwocr_gemm_skinny_w8)."""
     covered = {_gemm_variant(*c, w_tiled=2) for c in ops.DECODE_GEMM_CASES_W8}
+    _, attn = _covered()
+    # the E4M3 KV cache of 256-wide heads: tests/test_kv_fp8_gpu.py runs the fused step with and without splits / arrival counters
+    attn |= {_attn_plan_variant_e4m3(ns, arrive) for ns, arrive in ((1, False), (4, False), (4, True), (3, False), (3, True))}
     cfg = engine.preset(preset)
     missing = []
     for reads in READS:
         plan = engine.decode_plan(cfg, reads, fp8=True)
+        if plan["attn"] not in attn:
+            missing.append((reads, "attn", plan["attn"]))
         for name in engine.DECODE_GEMMS:
             if plan[name][4] not in covered:
                 missing.append((reads, name) + plan[name])

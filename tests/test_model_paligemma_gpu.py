@@ -81,13 +81,17 @@ def test_graph_decode_equals_eager(eng):
 
 # ---------------------------------------------------------------------------------------------- E4M3 wide GEMMs (config 4)
 # fp8_decode: the decode GEMMs and the LM head on E4M3 weight codes too (opt-in: exact but measured slower, engine.ReadEngine)
-@pytest.fixture(scope="module", params=[False, True], ids=["prefill_fp8", "prefill+decode_fp8"])
+# fp8_kv: the E4M3 KV cache of the 256-wide heads (round 4; the default with fp8: the decode attention streams half the bytes)
+@pytest.fixture(scope="module", params=[(False, True), (True, True), (False, False)], ids=["prefill_fp8+kv8", "prefill+decode_fp8+kv8", "prefill_fp8,bf16_kv"])
 def eng8(request):
     from handwritten_ocr_amd import engine
 
     sd = load_file(os.path.join(GOLD, "paligemma_tiny_weights.safetensors"))
+    fp8_decode, fp8_kv = request.param
     e = engine.ReadEngine(engine.preset("tinypg"), sd, max_reads=8, ctx=256, vit_batch=2, prefill_batch=2, fp8=True,
-                          fp8_decode=request.param)
+                          fp8_decode=fp8_decode, fp8_kv=fp8_kv)
+    assert e.fp8_kv == fp8_kv and bool(e.kv.fp8) == fp8_kv and (e.k_cache.dtype == torch.uint8) == fp8_kv
+    request = type("P", (), {"param": fp8_decode})   # (the assertions below speak of fp8_decode)
     assert e.fp8_decode == request.param and bool(e.dec.lm_head8t.w) == request.param
     # every LAYER GEMM too (the byte-tiled codes were never bound, so only the LM head ran on E4M3): tinypg's widths
     # (hidden 256, 2 x 256 attention, inter 512) are all multiples of 128, so each of the four has its E4M3 decode copy
@@ -104,7 +108,7 @@ def test_fp8_engine_stays_near_hf_bf16(eng8):
     tower's out_proj / fc2 and every prefill GEMM of the decoder in E4M3 (per-token activation scales, per-feature weight
     scales) the teacher-forced logits stay within mean 2e-2 / max 1.5e-1 of the logit scale of the HF bf16 goldens
     (measured on the MI355X: mean 5e-3, max 4e-2; the bf16 engine: 8e-4 / 7e-3) and every decisive step (HF top-1 margin
-    > 0.5) picks HF's token.  The kernels themselves are exact against oracle/fp8_ref.py (tests/test_ops_gpu.py)."""
+    > 0.5) picks HF's token — with the E4M3 KV cache (the default of the fp8 engine) as without it.  The kernels themselves are exact against oracle/fp8_ref.py (tests/test_ops_gpu.py)."""
     g = _gold()
     n = load_json("paligemma_tiny.json")["cases"]["a"]["n_new"]
     for c in ("a", "b"):

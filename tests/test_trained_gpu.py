@@ -146,14 +146,18 @@ def test_the_drop_in_transcribes_within_the_cer_bar(trained, tmp_path, monkeypat
 def test_fp8_leg_of_config_4_on_the_trained_paligemma():
     """BASELINE config 4's fp8 leg has no HF counterpart (parity unpinned: DESIGN.md §5) — but its effect on the OUTPUT can be put
     next to the accuracy bar: the trained tiny PaliGemma read with E4M3 operands in the wide GEMMs (every Linear of the tower / prefill
-    whose K is a multiple of 128: here the Gemma prefill; decode steps stay bf16) against HF's bf16 text of the same pages.  A stated
+    whose K is a multiple of 128: here the Gemma prefill; decode GEMMs stay bf16) AND an E4M3 KV cache (one scale per cached token),
+    against HF's bf16 text of the same pages.  A stated
     tolerance of this repo, the same 0.5 % CER; measured on the first run: see the printed line."""
+    import torch
+
     from handwritten_ocr_amd import engine, tokenizer
 
     family = "paligemma"
     meta, ckpt = trained_meta(family), trained_dir(family)
     cfg, sd = engine.load_checkpoint_dir(ckpt, device="cuda")
     eng = engine.ReadEngine(cfg, sd, max_reads=32, ctx=512, vit_batch=12, prefill_batch=16, fp8=True)
+    assert eng.fp8_kv and eng.k_cache.dtype == torch.uint8, "the fp8 engine of a 256-wide-head model keeps an E4M3 KV cache"
     try:
         proc = tokenizer.Processor(cfg, tokenizer.HFTokenizer(cfg, ckpt), template_dir=ckpt)
         prepared = [proc.prepare(Image.fromarray(trained_page(c), "RGB"), meta["prompt"]) for c in meta["cases"]]

@@ -144,6 +144,8 @@ def covered() -> set:
         lines += _plan(lambda lib: lib.hwocr_mrope_kv_prefill(ONE, ONE, ONE, ONE, ONE, ONE, ONE, 128, 64, 4, 2, 16, 40, 8, 8, 8, 8, 64, hd, tiled,
                                                               None))
     lines += _plan(lambda lib: lib.hwocr_embed_splice(ONE, ONE, ONE, ONE, ONE, 64, 256, 1.0, None))           # test_embed_splice
+    # tests/test_kv_fp8_gpu.py::test_kv_quant_fp8_codes_scales_and_layout (the prefill's fill of the E4M3 KV cache)
+    lines += _plan(lambda lib: lib.hwocr_kv_quant_fp8(ONE, ONE, 8, 8, 8, 8, 4160, ONE, ONE, ONE, ONE, 2, 2, 4160, 4224, None))
     eos = (C.c_int * 4)(1, 0, 0, 0)
     lines += _plan(lambda lib: lib.hwocr_argmax_advance(ONE, 512, 512, 4, ONE, ONE, ONE, ONE, ONE, 8, 0, eos, 1, 0, None, 0, 1.0, None, None))
     # test_argmax_* at V = 151936 with split_ws: 16 workgroups per read, the last one finishing
