@@ -29,6 +29,15 @@ def randbf(*shape, scale=1.0, seed=None):
     return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
 
 
+def randf32(*shape, seed=0):
+    """fp32 N(0, 1) on the device from a SEEDED host generator: a test's data must not depend on which tests ran before it (the device
+    RNG's state does; round 4: an unseeded torch.randn(..., device=...) made test_add_rmsnorm's data, and with it a one-in-a-million
+    rounding coincidence, a function of the test order)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(DEV)
+
+
 def assert_close_bf16(got: torch.Tensor, want_f32: torch.Tensor, ulps: float = 2.0, atol: float = 1e-3, what="",
                       mag: torch.Tensor | None = None):
     """got: bf16 kernel output; want: fp32 reference.  1 bf16 ulp of x = 2^(floor(log2|x|) - 7).

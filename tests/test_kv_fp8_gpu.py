@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests._gpu_util import DEV, assert_close_bf16, lib, p, randbf, rbf, st  # noqa: E402
+from tests._gpu_util import DEV, assert_close_bf16, lib, p, randbf, randf32, rbf, st  # noqa: E402
 from tests.test_ops_gpu import _rope_tables, _sdpa_ref  # noqa: E402
 
 HD = 256
@@ -87,7 +87,7 @@ def test_attn_decode_qkv_over_the_e4m3_cache(Hq, Hkv, nsplit, B):
     lens[0], lens[1], lens[2], lens[3] = 1, ctx, 33, 64
     delta = torch.randint(-1, 300, (B,), generator=g).tolist()
     delta[0] = 0
-    slabs = torch.randn(nslab, B, W, device=DEV)
+    slabs = randf32(nslab, B, W, seed=901)
     cos_t, sin_t = _rope_tables(max_pos, hd=HD)
     cos_d, sin_d = cos_t.to(DEV), sin_t.to(DEV)
     k = randbf(B, Hkv, ctx, HD, seed=16)
