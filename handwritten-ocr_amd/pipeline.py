@@ -87,13 +87,16 @@ class _JobHooks:
 
 
 class LanePipeline:
-    def __init__(self, engine, lanes: int = 2, order: str = "lockstep"):
+    def __init__(self, engine, lanes: int = 2, order: str = "lockstep", reuse: list | None = None):
+        """reuse: lanes of `engine` made earlier (another pipeline's engines[1:], which this one takes over) - a pipeline that grows
+        from two lanes to three allocates ONE more KV cache, not two."""
         if lanes < 1:
             raise ValueError("lanes must be >= 1")
         if order not in ("lockstep", "alternate"):
             raise ValueError("order must be 'lockstep' or 'alternate'")
         self.order = order
-        self.engines = [engine] + [engine.lane() for _ in range(lanes - 1)]
+        have = list(reuse or [])[: lanes - 1]
+        self.engines = [engine] + have + [engine.lane() for _ in range(lanes - 1 - len(have))]
         self.device = engine.dev
         # (no device: the thread / ordering logic alone, for the CPU test of it — a ReadEngine always has one)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in self.engines] if self.device is not None else None

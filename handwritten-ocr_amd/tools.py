@@ -90,10 +90,10 @@ def _lib_error(msg: str):
     return _lib.HwocrError(msg)
 
 
-_ocr_lanes: dict = {}  # lanes -> pipeline.LanePipeline over _ocr_model, made on the first batch that needs that many
+_ocr_lanes = None  # pipeline.LanePipeline over _ocr_model: as many lanes as the largest job so far needed (2, or 3)
 
 
-def plan_lanes(n_reads: int, slots: int, lanes_cfg: int) -> tuple[int, int]:
+def plan_lanes(n_reads: int, slots: int, lanes_cfg: int, allow_three: bool = True) -> tuple[int, int]:
     """(lanes, decode slots to use per lane) for a job of n_reads reads on lanes of `slots` decode slots, lanes_cfg = HWOCR_LANES.
     A job that fits one lane runs on one.  Otherwise the reads make `batches` = ceil(n / slots) slot-fills; two lanes take them side
     by side in rounds - unless the job is THREE fills (or an odd multiple of three), which three lanes take in one round instead of
@@ -104,7 +104,7 @@ def plan_lanes(n_reads: int, slots: int, lanes_cfg: int) -> tuple[int, int]:
     if batches <= 1 or lanes_cfg <= 1:
         return 1, slots
     lanes = lanes_cfg
-    if lanes_cfg == 2 and batches % 2 == 1 and batches % 3 == 0:
+    if allow_three and lanes_cfg == 2 and batches % 2 == 1 and batches % 3 == 0:
         lanes = 3
     rounds = -(-batches // lanes)
     per = slots if rounds > 4 else min(slots, -(-n_reads // (rounds * lanes)))
@@ -112,26 +112,29 @@ def plan_lanes(n_reads: int, slots: int, lanes_cfg: int) -> tuple[int, int]:
 
 
 def _lanes(n: int | None = None):
-    """n (default HWOCR_LANES = 2) sets of read slots over the loaded weights, each on its own stream and host thread: a batch with
-    more reads than one lane has slots goes through them side by side (pipeline.py: +6 % pages/s on the MI355X, same tokens).
+    """At least n (default HWOCR_LANES = 2) sets of read slots over the loaded weights, each on its own stream and host thread: a batch
+    with more reads than one lane has slots goes through them side by side (pipeline.py: +6 % pages/s on the MI355X, same tokens).
+    ONE pipeline is kept and grown when a job needs a third lane (a job with fewer jobs than lanes leaves the last lanes idle).
     None: one lane."""
+    global _ocr_lanes
     n = int(os.environ.get("HWOCR_LANES", "2")) if n is None else n
     if n <= 1 or _ocr_model is None:
         return None
-    pipe = _ocr_lanes.get(n)
-    if pipe is None or pipe.engines[0] is not _ocr_model:
+    if _ocr_lanes is not None and _ocr_lanes.engines[0] is not _ocr_model:
+        _ocr_lanes.close()
+        _ocr_lanes = None
+    if _ocr_lanes is None or len(_ocr_lanes.engines) < n:
         from . import pipeline
 
-        if pipe is not None:
-            pipe.close()
-        pipe = _ocr_lanes[n] = pipeline.LanePipeline(_ocr_model, lanes=n)
-    return pipe
+        _ocr_lanes = pipeline.LanePipeline(_ocr_model, lanes=n, reuse=_ocr_lanes.engines[1:] if _ocr_lanes is not None else None)
+    return _ocr_lanes
 
 
 def _close_lanes() -> None:
-    for pipe in _ocr_lanes.values():
-        pipe.close()
-    _ocr_lanes.clear()
+    global _ocr_lanes
+    if _ocr_lanes is not None:
+        _ocr_lanes.close()
+    _ocr_lanes = None
 
 
 def unload_ocr_model():
@@ -180,8 +183,18 @@ def run_ocr_batch_tokens(images: list, params: dict | None = None, on_done=None)
     # (read_ids: the caller's numbering of the reads - it keys the sampling RNG, so that a sampled read does not depend on the shard)
     rp = params.get("repetition_penalty")  # None: the checkpoint's default
     ids = params.get("read_ids")
-    n_lanes, per_lane = plan_lanes(len(pages), model.max_reads, int(os.environ.get("HWOCR_LANES", "2")))
-    pipe = _lanes(n_lanes) if n_lanes > 1 else None
+    lanes_cfg = int(os.environ.get("HWOCR_LANES", "2"))
+    n_lanes, per_lane = plan_lanes(len(pages), model.max_reads, lanes_cfg)
+    try:
+        pipe = _lanes(n_lanes) if n_lanes > 1 else None
+    except RuntimeError as e:   # a third lane's KV cache did not fit beside the other two (a big model at a long context): two lanes
+        import torch
+
+        if n_lanes <= lanes_cfg or not isinstance(e, torch.cuda.OutOfMemoryError):
+            raise
+        torch.cuda.empty_cache()
+        n_lanes, per_lane = plan_lanes(len(pages), model.max_reads, lanes_cfg, allow_three=False)
+        pipe = _lanes(n_lanes) if n_lanes > 1 else None
     if pipe is None:
         return model.generate_stream(pages, prompts, max_new=max_new, min_new=min_new, repetition_penalty=rp, read_ids=ids,
                                      on_done=on_done)
@@ -193,7 +206,7 @@ def run_ocr_batch_tokens(images: list, params: dict | None = None, on_done=None)
     ids = list(range(len(pages))) if ids is None else list(ids)
     src = _engine.ReadSource(len(pages))
     jobs = [(lambda e, hooks: e.generate_stream(pages, prompts, max_new=max_new, min_new=min_new, repetition_penalty=rp, read_ids=ids,
-                                                on_done=on_done, source=src, max_slots=per_lane)) for _ in pipe.engines]
+                                                on_done=on_done, source=src, max_slots=per_lane)) for _ in range(n_lanes)]
     parts = pipe.run(jobs)
     out = [next((part[i] for part in parts if part[i] is not None), None) for i in range(len(pages))]
     if any(t is None for t in out):

@@ -355,21 +355,23 @@ def test_run_ocr_batch_deals_reads_over_two_lanes(tmp_path, monkeypatch):
     monkeypatch.setenv("HWOCR_KEEP_RESIDENT", "0")
     monkeypatch.setattr(tools, "_ocr_model", None)
     monkeypatch.setattr(tools, "_ocr_processor", None)
-    monkeypatch.setattr(tools, "_ocr_lanes", {})
+    monkeypatch.setattr(tools, "_ocr_lanes", None)
     monkeypatch.setattr(config, "OCR_MIN_PIXELS", 28 * 28)
     imgs = [Image.fromarray(make_page(60 + i, 70 + 14 * (i % 3), 100), "RGB") for i in range(20)]
     params = {"max_new_tokens": 10, "min_new_tokens": 3}
     monkeypatch.setenv("HWOCR_LANES", "1")
     want = tools.run_ocr_batch_tokens(imgs, params)
-    assert tools._ocr_lanes == {}
+    assert tools._ocr_lanes is None
     monkeypatch.setenv("HWOCR_LANES", "2")
     got = tools.run_ocr_batch_tokens(imgs, params)                    # 20 reads / 6 slots: 4 fills -> two lanes, two rounds of 5
     assert tools.plan_lanes(20, 6, 2) == (2, 5)
-    assert set(tools._ocr_lanes) == {2} and len(tools._ocr_lanes[2].engines) == 2
+    assert len(tools._ocr_lanes.engines) == 2
+    second = tools._ocr_lanes.engines[1]
     assert got == want and len(got) == 20
     assert tools.plan_lanes(17, 6, 2) == (3, 6)
     assert tools.run_ocr_batch_tokens(imgs[:17], params) == want[:17]  # 3 fills: three lanes, one round
-    assert set(tools._ocr_lanes) == {2, 3} and len(tools._ocr_lanes[3].engines) == 3
+    assert len(tools._ocr_lanes.engines) == 3 and tools._ocr_lanes.engines[1] is second, "the pipeline grew by ONE lane"
+    assert tools.run_ocr_batch_tokens(imgs, params) == want            # a two-lane job on the three-lane pipeline
     assert tools.run_ocr_batch_tokens(imgs[:5], params) == want[:5]   # fits one lane: no dealing
     tools._ocr_model.cfg.do_sample, tools._ocr_model.cfg.temperature, tools._ocr_model.cfg.top_k = True, 1.0, 20
     a = tools.run_ocr_batch_tokens(imgs, params)
@@ -377,7 +379,7 @@ def test_run_ocr_batch_deals_reads_over_two_lanes(tmp_path, monkeypatch):
     b = tools.run_ocr_batch_tokens(imgs, params)
     assert a == b and a != want
     tools.unload_ocr_model()
-    assert tools._ocr_model is None and tools._ocr_lanes == {}
+    assert tools._ocr_model is None and tools._ocr_lanes is None
 
 
 def test_batch_folder_cli_end_to_end(tmp_path, monkeypatch, capsys):

@@ -64,7 +64,7 @@ if rank == 0:
           f"{1e3 * stats['writer_tail_s']:.0f} ms of it left after the last read stopped")
     print(f"  read_pages: host preparation {batch.LAST_READ_TIMINGS.get('prepare_s', 0):.2f} s, engine pass {batch.LAST_READ_TIMINGS.get('engine_s', 0):.2f} s")
     if os.environ.get("HWOCR_FOLDER_TRACE"):
-        engines = tools._lanes(n_lanes).engines if n_lanes > 1 else [model]
+        engines = tools._lanes(n_lanes).engines[:n_lanes] if n_lanes > 1 else [model]
         for li, e in enumerate(engines):
             tr = getattr(e, "stream_trace", [])
             adm = [(n, round(ms)) for n, ms in tr if n]
