@@ -62,3 +62,25 @@ mhz = [(float(raw[b, per[b] - 1, 3]) - float(raw[b, 0, 3])) / ((float(raw[b, per
 print(f"  shader clock while the kernel runs (s_memtime ticks per wall-clock us): mean {np.mean(mhz):.0f} MHz")
 ideal = 2.0 * 256 * 256 * K / (2.5e15 / 256) * 1e6
 print(f"  MFMA time of one tile at the 2.5 PF peak: {ideal:.2f} us")
+
+# ---- what a work queue could buy: every workgroup's own mean time per tile (loop + epilogue + hand-over), and the same tiles dealt
+# to the same workgroups (a) round-robin as the kernel does, (b) from one queue in the order workgroups come free (list scheduling)
+per_tile = np.array([(t[b, per[b] - 1, 2] - t[b, 0, 0]) / per[b] if per[b] else np.nan for b in range(cus)])
+ok = ~np.isnan(per_tile)
+print(f"  time per tile by workgroup: mean {np.nanmean(per_tile):.2f} us, min {np.nanmin(per_tile):.2f}, p10 {np.nanpercentile(per_tile, 10):.2f}, "
+      f"p90 {np.nanpercentile(per_tile, 90):.2f}, max {np.nanmax(per_tile):.2f}")
+for x in range(8):
+    v = per_tile[x::8]
+    print(f"    workgroups = {x} mod 8: {np.nanmean(v):6.2f} us per tile (min {np.nanmin(v):.2f}, max {np.nanmax(v):.2f})")
+static = max(per[b] * per_tile[b] for b in range(cus) if per[b])
+import heapq
+heap = [(0.0, b) for b in range(cus) if ok[b]]
+heapq.heapify(heap)
+end = 0.0
+for _ in range(tiles):
+    at, b = heapq.heappop(heap)
+    at += per_tile[b]
+    end = max(end, at)
+    heapq.heappush(heap, (at, b))
+print(f"  span with each workgroup's own mean tile time: round-robin {static:.1f} us, one queue {end:.1f} us ({100 * (1 - end / static):.1f} % less); "
+      f"work / workgroups = {tiles * np.nanmean(per_tile) / ok.sum():.1f} us")
